@@ -1,0 +1,102 @@
+"""Seeded synthetic KEEP weights in the release ``state_dict`` key layout.
+
+There are no KEEP weights in this environment (no network), so every parity
+test and the benchmark run on these.  The key layout is the one
+``load_state_dict(strict=True)`` at ``quick_start/keep_inference.py:82-83``
+expects.  Distributions follow SURVEY.md §8(d): linear
+W~N(0,0.02..0.03), small biases, LN gamma 1±0.1, and LayerScale gamma drawn
+from U(0.05,0.5) -- timm's init_values=1e-5 would make every block a no-op and
+parity trivially true.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .config import KEEPShape
+
+
+def synth_state_dict(shape: KEEPShape = KEEPShape(), seed: int = 0,
+                     vision: bool = True, text: bool = True) -> Dict[str, torch.Tensor]:
+    g = torch.Generator(device="cpu").manual_seed(seed)
+
+    def normal(*size, std=0.02):
+        return torch.randn(*size, generator=g, dtype=torch.float32) * std
+
+    def uniform(*size, lo=0.0, hi=1.0):
+        return torch.rand(*size, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+    def ln(prefix, n, sd):
+        sd[prefix + ".weight"] = 1.0 + normal(n, std=0.1)
+        sd[prefix + ".bias"] = normal(n, std=0.05)
+
+    def linear(prefix, out_f, in_f, sd, std=0.025):
+        sd[prefix + ".weight"] = normal(out_f, in_f, std=std)
+        sd[prefix + ".bias"] = normal(out_f, std=0.02)
+
+    sd: Dict[str, torch.Tensor] = {}
+    sd["logit_scale"] = torch.tensor(shape.logit_scale_init, dtype=torch.float32)
+    if vision:
+        v = shape.vision
+        d = v.embed_dim
+        sd["visual.cls_token"] = normal(1, 1, d)
+        sd["visual.pos_embed"] = normal(1, v.num_tokens, d)
+        sd["visual.patch_embed.proj.weight"] = normal(d, 3, v.patch_size, v.patch_size, std=0.03)
+        sd["visual.patch_embed.proj.bias"] = normal(d, std=0.02)
+        for i in range(v.depth):
+            p = f"visual.blocks.{i}."
+            ln(p + "norm1", d, sd)
+            linear(p + "attn.qkv", 3 * d, d, sd, std=0.03)
+            linear(p + "attn.proj", d, d, sd)
+            sd[p + "ls1.gamma"] = uniform(d, lo=0.05, hi=0.5)
+            ln(p + "norm2", d, sd)
+            linear(p + "mlp.fc1", v.mlp_dim, d, sd)
+            linear(p + "mlp.fc2", d, v.mlp_dim, sd, std=0.02)
+            sd[p + "ls2.gamma"] = uniform(d, lo=0.05, hi=0.5)
+        ln("visual.norm", d, sd)
+        linear("visual_head.0", shape.projection_dim, d, sd)
+        linear("visual_head.2", shape.projection_dim, shape.projection_dim, sd)
+    if text:
+        t = shape.text
+        h = t.hidden_size
+        sd["text.embeddings.word_embeddings.weight"] = normal(t.vocab_size, h)
+        sd["text.embeddings.position_embeddings.weight"] = normal(t.max_position_embeddings, h)
+        sd["text.embeddings.token_type_embeddings.weight"] = normal(t.type_vocab_size, h)
+        ln("text.embeddings.LayerNorm", h, sd)
+        for i in range(t.num_hidden_layers):
+            p = f"text.encoder.layer.{i}."
+            linear(p + "attention.self.query", h, h, sd, std=0.03)
+            linear(p + "attention.self.key", h, h, sd, std=0.03)
+            linear(p + "attention.self.value", h, h, sd)
+            linear(p + "attention.output.dense", h, h, sd)
+            ln(p + "attention.output.LayerNorm", h, sd)
+            linear(p + "intermediate.dense", t.intermediate_size, h, sd)
+            linear(p + "output.dense", h, t.intermediate_size, sd, std=0.02)
+            ln(p + "output.LayerNorm", h, sd)
+        linear("text.pooler.dense", h, h, sd)
+    return sd
+
+
+def synth_tiles(batch: int, seed: int = 0, dtype=torch.float32) -> torch.Tensor:
+    """ImageNet-normalised tiles are ~N(0,1); SURVEY.md §8(d) config 2."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(batch, 3, 224, 224, generator=g, dtype=torch.float32).to(dtype)
+
+
+def synth_prompts(n: int, seq: int = 256, seed: int = 1, vocab: int = 30522,
+                  min_len: int = 8, max_len: int = 32) -> Dict[str, torch.Tensor]:
+    """Token tensors shaped like the tokenizer call at keep_inference.py:99.
+
+    ``[CLS] w.. [SEP] [PAD]*`` with valid lengths ~U{min_len..max_len}
+    (SURVEY.md §8(d) config 3).  Ids are random: no vocab file exists here.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ids = torch.randint(4, vocab, (n, seq), generator=g, dtype=torch.int64)
+    lens = torch.randint(min_len, min(max_len, seq) + 1, (n,), generator=g)
+    pos = torch.arange(seq)[None, :]
+    mask = (pos < lens[:, None]).to(torch.int64)
+    ids[:, 0] = 2                                   # [CLS] in PubMedBERT's vocab
+    ids[torch.arange(n), lens - 1] = 3              # [SEP]
+    ids = ids * mask                                # [PAD] = 0
+    return {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": mask}
