@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 224x224 tiles encoded per second through the ViT-L/16 image tower
+(BASELINE.json configs[1]: batch 256 synthetic bf16 tiles per GPU, random-init weights).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = KEEPModel.encode_image on one batch of 256 device-resident tiles per rank (+ the RCCL
+all-gather of the [256,768] embeddings when N > 1: the slide-level pooling exchange of config 4).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from keep_amd import KEEPModel, PROFILE_TAGS, vit_flops_per_tile          # noqa: E402
+from keep_amd.config import KEEPShape                                      # noqa: E402
+from keep_amd.synth import synth_state_dict, synth_tiles                   # noqa: E402
+
+PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense
+DOMINANT_TAG = "vit.fc1"     # gemm_f16_nt_kernel<EPI_GELU_F16>: [B*197,1024] x [1024,4096], 32 % of the FLOPs
+
+
+T_START = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(sd, tiles: int = 8, iters: int = 3):
+    """The oracle (fp32 torch-CPU restatement of the reference's encode_image) on the host cores."""
+    from oracle import keep_oracle as O
+    torch.set_num_threads(min(usable_cpus(), 64))
+    x = synth_tiles(tiles, seed=0)
+    with torch.no_grad():
+        O.encode_image(sd, x[:1])                                   # warm-up
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(iters):
+            O.encode_image(sd, x)
+            done += 1
+            if time.perf_counter() - t0 > 30.0:                     # bounded sample
+                break
+        dt = time.perf_counter() - t0
+    iters = done
+    return {"value": round(tiles * iters / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} x {tiles} synthetic 224x224 tiles, fp32 torch-CPU restatement (oracle/keep_oracle.py) "
+                      f"of KEEPModel.encode_image, same synthetic weights; CPU: {cpu_model_name()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="tiles per GPU per step")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "strict"])
+    ap.add_argument("--pixel-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: keep_amd has no CPU execution path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    log(f"start: world={world} cpus={usable_cpus()} (os.cpu_count={os.cpu_count()})")
+    torch.set_num_threads(min(usable_cpus(), 16))
+    shape = KEEPShape()
+    sd = synth_state_dict(shape, seed=0, text=False)                 # identical weights on every rank
+    model = KEEPModel(shape, precision=args.precision)
+    model.load_state_dict(sd, strict=True)
+    model.to(dev).eval()
+    model.reserve(tiles=args.batch)
+    log("weights uploaded, workspace reserved")
+
+    B = args.batch
+    pix = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.pixel_dtype]
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)        # per-rank tiles, generated on device
+    tiles = torch.randn(B, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(pix)
+    gathered = torch.empty(world * B, shape.projection_dim, device=dev, dtype=torch.float32) if world > 1 else None
+
+    def step():
+        f = model.encode_image(tiles)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, f)
+        return f
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    log("warm-up done")
+    model.profile_enable(DOMINANT_TAG)
+    model.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    dom_ms, dom_n = model.profile_read(DOMINANT_TAG)
+    model.profile_disable()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    breakdown = None
+    if not args.no_breakdown and rank == 0:
+        model.profile_enable(None)
+        model.profile_reset()
+        for _ in range(2):
+            model.encode_image(tiles)
+        torch.cuda.synchronize(dev)
+        breakdown = {}
+        for tag in PROFILE_TAGS:
+            ms, n = model.profile_read(tag)
+            if n:
+                breakdown[tag] = round(ms / 2, 3)
+        model.profile_disable()
+
+    if rank == 0:
+        tiles_per_s = world * B * args.steps / elapsed
+        M = B * shape.vision.num_tokens
+        flops_launch = 2.0 * M * shape.vision.embed_dim * shape.vision.mlp_dim
+        avg_ms = dom_ms / max(dom_n, 1)
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if dom_n else 0.0
+        line = {
+            "metric": "224x224 tiles encoded/sec (whole node)", "value": round(tiles_per_s, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "fp16x3",
+            "data": "synthetic (randn tiles generated on device, seeded random-init weights)",
+            "config": {"workload": "ViT-L/16 image encoder only (KEEP encode_image), batch 256 synthetic 224x224 "
+                                   f"{args.pixel_dtype} tiles per GPU, 1xMI355X per rank",
+                       "tiles_per_gpu_per_step": B, "precision": args.precision,
+                       "exchange": "RCCL all_gather of [256,768] fp32 embeddings per step" if world > 1 else "none",
+                       "mfma_frac_end_to_end": round(tiles_per_s / world * vit_flops_per_tile() / (PEAK_F16_TFLOPS * 1e12), 4)},
+            "roofline": {"bound": "mfma", "kernel": "keepk::gemm_f16_nt_kernel<EPI_GELU_F16> (vit.fc1)",
+                         "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
+                         "flops_per_launch": flops_launch},
+        }
+        if breakdown is not None:
+            line["breakdown_ms_per_step"] = breakdown
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle on host cores) ...")
+            line["cpu_baseline"] = cpu_baseline(sd)
+            log("cpu baseline done")
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

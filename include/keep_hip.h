@@ -1,0 +1,149 @@
+/*
+ * libkeep_hip -- C ABI of the MI355X (gfx950) KEEP zero-shot inference engine.
+ *
+ * This is the drop-in boundary for the hot path of MAGIC-AI4Med/KEEP: everything below
+ * `KEEPModel.encode_image` / `encode_text` / the tile x prompt similarity.  Each entry point names
+ * the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - all functions return 0 on success or a negative KEEP_E* code; keep_last_error(h) gives text
+ *   - every data pointer is a raw DEVICE pointer on the handle's GPU unless stated otherwise
+ *     (e.g. torch.Tensor.data_ptr()); the caller owns all I/O buffers, the engine owns weights,
+ *     repacked fp16 planes and its workspace
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on
+ *     it, with no hidden device synchronisation once the workspace is large enough
+ *     (keep_reserve() up front avoids the allocation a first call would otherwise do)
+ *   - a handle is not thread-safe: one handle per GPU per host thread
+ *   - no torch / C++ types cross this boundary
+ */
+#ifndef KEEP_HIP_H
+#define KEEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct keep_handle keep_handle;
+
+enum {
+    KEEP_OK = 0,
+    KEEP_EINVAL = -1,       /* bad argument / shape / dtype                                  */
+    KEEP_ESTATE = -2,       /* call out of order (weights not finalised, ...)                */
+    KEEP_EKEY = -3,         /* unexpected or missing state_dict key (load_state_dict strict) */
+    KEEP_EHIP = -4,         /* HIP runtime error                                             */
+    KEEP_EUNSUPPORTED = -5, /* shape outside what the kernels implement                      */
+    KEEP_ENOMEM = -6
+};
+
+/* pixel dtypes accepted by keep_encode_image */
+enum { KEEP_PIX_F32 = 0, KEEP_PIX_F16 = 1, KEEP_PIX_BF16 = 2 };
+
+/* similarity modes */
+enum {
+    KEEP_SIM_RAW = 0,         /* out f32 [N,P] = scale * img @ txt^T          keep_inference.py:104          */
+    KEEP_SIM_ARGMAX = 1,      /* RAW + argmax_out int32 [N] (out may be NULL)                                */
+    KEEP_SIM_SOFTMAX = 2,     /* out f32 [N,P] = softmax(scale*cos, dim=1)    subtyping_utils.py:72 (scale 10)*/
+    KEEP_SIM_SOFTMAX_F16 = 3, /* same, out fp16 [N,P]                          (BASELINE config 5)            */
+    KEEP_SIM_TOP2SCORE = 4    /* out f32 [1] = mean_t[(v1-v2)-|v1+v2-1|]      WSI_evaluation/utils.py:107-117 */
+};
+
+/* precision modes (keep_set_option "precision") */
+enum {
+    KEEP_PREC_FP16 = 0,   /* fp16 MFMA operands, fp32 accumulate, fp32 residual/LN/softmax/GELU    */
+    KEEP_PREC_STRICT = 1  /* hi/lo split operands, 3 MFMA passes: fp32-class accuracy, ~1/3 speed   */
+};
+
+const char* keep_version(void);
+
+/* ---- lifetime ---------------------------------------------------------------------------------
+ * Replaces: `AutoModel.from_config(config)` + `.to(device)`  (quick_start/keep_inference.py:81,
+ * WSI_evaluation/zeroshot_subtyping_WSI.py:44-46). */
+int keep_create(int device_id, keep_handle** out);
+int keep_destroy(keep_handle* h);
+const char* keep_last_error(keep_handle* h);
+
+/* ---- weights ----------------------------------------------------------------------------------
+ * Replaces: `model.load_state_dict(state_dict, strict=True)`  (quick_start/keep_inference.py:82-83).
+ * Call keep_load_tensor once per state_dict entry using the release key names (SURVEY.md A.3:
+ * "visual.blocks.3.attn.qkv.weight", "text.encoder.layer.0.attention.self.query.weight", ...),
+ * fp32 data, then keep_finalize_weights(), which fails with KEEP_EKEY if any expected key is missing
+ * (strict semantics).  Data is copied / repacked; the caller's buffer may be freed afterwards.
+ * `on_device` != 0: `data` is a device pointer on the handle's GPU; 0: host pointer. */
+int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndim, const int64_t* shape,
+                     int on_device);
+int keep_finalize_weights(keep_handle* h);
+/* after finalize: depth / layer counts actually loaded (0 if that tower was not loaded) */
+int keep_vit_depth(keep_handle* h);
+int keep_bert_layers(keep_handle* h);
+
+/* ---- options ----------------------------------------------------------------------------------
+ *   "precision"       KEEP_PREC_FP16 (default) | KEEP_PREC_STRICT
+ *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
+ *   "max_tiles"       tiles per internal sub-batch of keep_encode_image (default 256)
+ *   "max_prompts"     prompts per internal sub-batch of keep_encode_text (default 64)
+ */
+int keep_set_option(keep_handle* h, const char* name, double value);
+double keep_get_option(keep_handle* h, const char* name);
+
+/* Pre-allocate workspace for calls of up to `tiles` tiles and `prompts` x `seq` tokens. */
+int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq);
+int64_t keep_workspace_bytes(keep_handle* h);
+
+/* ---- the hot path -----------------------------------------------------------------------------
+ * Replaces: KEEPModel.encode_image  (quick_start/keep_inference.py:54-58)
+ *   pixels: [B,3,224,224] NCHW, ImageNet-normalised, dtype per `pix_dtype`; out: fp32 [B,768],
+ *   L2-normalised (F.normalize semantics). */
+int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, float* out, void* stream);
+
+/* Replaces: KEEPModel.encode_text  (quick_start/keep_inference.py:60-62)
+ *   input_ids / token_type_ids / attention_mask: int64 [P,T] (the tokenizer's return_tensors='pt'
+ *   layout, keep_inference.py:99); token_type_ids and attention_mask may be NULL (zeros / ones, as
+ *   HF BertModel defaults).  out: fp32 [P,768] L2-normalised.  T <= 512 (256 in strict mode). */
+int keep_encode_text(keep_handle* h, const int64_t* input_ids, const int64_t* token_type_ids,
+                     const int64_t* attention_mask, int64_t P, int64_t T, float* out, void* stream);
+
+/* 1 if any token / type id of the most recent keep_encode_text on `stream` was out of range (the
+ * kernel clamps it; the reference's nn.Embedding would raise IndexError).  Synchronises `stream`. */
+int keep_token_error(keep_handle* h, void* stream);
+
+/* Replaces: `img_feature @ text_feature.T` (keep_inference.py:104), `image_features @ cls`
+ * (WSI_evaluation/utils.py:128) and the softmax / top-2 score that follow it in the WSI scripts.
+ *   img fp32 [N,D], txt fp32 [P,D] (row-major; a reference classifier [D,C] is passed transposed). */
+int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t N, int64_t P, int64_t D,
+                    float scale, int mode, void* out, int32_t* argmax_out, void* stream);
+
+/* ---- profiling (HIP events on the launch stream) ----------------------------------------------
+ * tag names: "vit.im2col" "vit.patch" "vit.ln" "vit.qkv" "vit.attn" "vit.proj" "vit.fc1" "vit.fc2"
+ * "vit.head" "text.embed" "text.ln" "text.qkv" "text.attn" "text.out" "text.ffn1" "text.ffn2"
+ * "text.pool" "sim".  keep_profile_enable(h, NULL) times every tag, a name times only that tag,
+ * "" disables.  keep_profile_read synchronises the recorded events and returns the accumulated
+ * milliseconds and launch count for `tag` since the last keep_profile_reset. */
+int keep_profile_enable(keep_handle* h, const char* tag_or_null);
+int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches);
+int keep_profile_reset(keep_handle* h);
+
+/* ---- single-operator entry points (used by the parity tests; fp32 in/out on device) -----------
+ * keep_op_linear: out = epilogue(A[M,K] @ W[N,K]^T + bias) through the fp16 MFMA GEMM.
+ *   epi 0: out[M,N] = acc+bias            1: gelu(acc+bias)
+ *       2: out = resid + ls*(acc+bias)    4: out = resid + acc + bias      (resid, ls fp32)
+ *   split != 0 runs the 3-pass hi/lo product.  Outputs of epi 0/1 are the fp16-rounded values
+ *   (hi, or hi+lo in split mode) converted back to fp32. */
+int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls,
+                   const float* resid, int64_t M, int64_t N, int64_t K, int epi, int split, float* out,
+                   void* stream);
+/* qkv fp32 [B*T, 3*heads*64] (q|k|v), mask int64 [B,T] or NULL -> out fp32 [B*T, heads*64] */
+int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int64_t B, int64_t T, int heads,
+                      int split, float* out, void* stream);
+int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const float* gamma, const float* beta,
+                      int64_t rows, int64_t D, float eps, float* out, void* stream);
+/* out[M,N] = act(scale * A[M,K] @ B[N,K]^T + bias); act 0 none, 1 gelu, 2 tanh (exact fp32 MFMA) */
+int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* bias, int64_t M, int64_t N,
+                  int64_t K, float scale, int act, float* out, void* stream);
+int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEEP_HIP_H */

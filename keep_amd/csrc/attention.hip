@@ -1,0 +1,273 @@
+// Whole-sequence softmax attention for short sequences (ViT: 197 tokens, BERT: <=512), gfx950.
+//
+//   out[b, t, h*64:(h+1)*64] = softmax(q k^T / 8 + key_bias) v        per (b, h)
+//
+// Reference arithmetic: timm Attention.forward (scaled_dot_product_attention, no mask) -- SURVEY.md
+// §A.1; HF BertSelfAttention with the key-padding additive mask -- §A.2.
+//
+// Layout / mapping:
+//   * one workgroup (4 wavefronts) per (batch, head); K (row-major, XOR-swizzled 16-B slots) and
+//     V^T (feature-major, padded rows) of that head live in LDS for the whole workgroup
+//   * each wavefront owns 16 query rows at a time and computes S^T = K Q^T with
+//     mfma_f32_16x16x32_f16 (A operand = K rows from LDS, B operand = Q rows from HBM), so a lane
+//     holds, for ONE query (lane&15), the scores of keys {16t + 4*(lane>>4) + r}: the softmax
+//     reduction is in-register plus two cross-lane steps (xor 16, xor 32)
+//   * the same registers, converted to fp16, ARE the B operand of  O^T = V^T P^T  (the key
+//     permutation they imply is applied to the V^T fragment reads instead): no P round trip
+//   * normalisation by 1/sum is applied to the fp32 O accumulators
+//   * SPLIT mode (strict precision) runs hi/lo products: QhKh+QlKh+QhKl and PhVh+PlVh+PhVl
+#include "common.h"
+
+namespace keepk {
+
+constexpr int ATT_THREADS = 256;
+constexpr int HD = 64;
+
+__host__ __device__ constexpr int att_kp2(int NT) { return ((NT + 1) / 2) * 32; }
+__host__ __device__ constexpr int att_vs(int NT) { return att_kp2(NT) + 8; }          // V^T row stride (f16)
+__host__ __device__ constexpr size_t att_lds_bytes(int NT, bool split) {
+    size_t one = (size_t)NT * 16 * HD * 2 + (size_t)HD * att_vs(NT) * 2;
+    return one * (split ? 2 : 1) + (size_t)NT * 16 * 4;
+}
+
+__device__ __forceinline__ unsigned sel4(const uint4& x, int i) {
+    return i == 0 ? x.x : (i == 1 ? x.y : (i == 2 ? x.z : x.w));
+}
+
+template <int NT>
+__device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok, int D3, int koff, int voff,
+                                         f16* sK, f16* sVt, int tid) {
+    // Branch-free staging: out-of-range work items are clamped onto the last valid item (they rewrite
+    // identical bytes) and rows >= ntok are loaded from row ntok-1 and then zeroed with a select.
+    constexpr int NKP = NT * 16;
+    constexpr int VS = att_vs(NT);
+    constexpr int NPAIR = att_kp2(NT) / 2;
+    constexpr int K_ITEMS = NKP * 8, V_ITEMS = NPAIR * 8;
+    constexpr int K_IT = (K_ITEMS + ATT_THREADS - 1) / ATT_THREADS;
+    constexpr int V_IT = (V_ITEMS + ATT_THREADS - 1) / ATT_THREADS;
+    const uint4 zero = {0, 0, 0, 0};
+#pragma unroll 2
+    for (int it = 0; it < K_IT; ++it) {
+        int idx = tid + it * ATT_THREADS;
+        idx = idx < K_ITEMS ? idx : K_ITEMS - 1;
+        const int row = idx >> 3, c = idx & 7;
+        const int rc = row < ntok ? row : ntok - 1;
+        uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)rc * D3 + koff + c * 8);
+        v = row < ntok ? v : zero;
+        *reinterpret_cast<uint4*>(sK + row * HD + ((c ^ ((row >> 1) & 7)) << 3)) = v;
+    }
+#pragma unroll 2
+    for (int it = 0; it < V_IT; ++it) {
+        int idx = tid + it * ATT_THREADS;
+        idx = idx < V_ITEMS ? idx : V_ITEMS - 1;
+        const int kp = idx >> 3, c = idx & 7;
+        const int k0 = 2 * kp, k1 = 2 * kp + 1;
+        const int r0 = k0 < ntok ? k0 : ntok - 1, r1 = k1 < ntok ? k1 : ntok - 1;
+        uint4 a = *reinterpret_cast<const uint4*>(base + (int64_t)r0 * D3 + voff + c * 8);
+        uint4 b = *reinterpret_cast<const uint4*>(base + (int64_t)r1 * D3 + voff + c * 8);
+        a = k0 < ntok ? a : zero;
+        b = k1 < ntok ? b : zero;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = (r + c) & 7;                  // rotate so the 8 lanes of a key pair hit 8 banks
+            const unsigned wa = sel4(a, e >> 1), wb = sel4(b, e >> 1);
+            const int sh = (e & 1) * 16;
+            const unsigned packed = ((wa >> sh) & 0xffffu) | (((wb >> sh) & 0xffffu) << 16);
+            *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * VS + k0) = packed;
+        }
+    }
+}
+
+template <int NT, bool SPLIT>
+__global__ __launch_bounds__(ATT_THREADS, 2)
+void attention_kernel(AttnParams p) {
+    constexpr int NKP = NT * 16;
+    constexpr int VS = att_vs(NT);
+    constexpr int NU = (NT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f16* sK = reinterpret_cast<f16*>(smem);
+    f16* sVt = sK + NKP * HD;
+    float* sBias = reinterpret_cast<float*>(sVt + HD * VS);
+    f16* sKl = reinterpret_cast<f16*>(sBias + NKP);
+    f16* sVtl = sKl + NKP * HD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
+    const int ntok = p.ntok;
+    const int D = p.heads * HD, D3 = 3 * D;
+    const int64_t tok0 = (int64_t)b * ntok;
+    const f16* base_hi = p.qkv_hi + tok0 * D3;
+    const f16* base_lo = SPLIT ? p.qkv_lo + tok0 * D3 : nullptr;
+
+    stage_kv<NT>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid);
+    if (SPLIT) stage_kv<NT>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid);
+    for (int k = tid; k < NKP; k += ATT_THREADS) {
+        float bias = 0.f;
+        if (k >= ntok) bias = -INFINITY;
+        else if (p.mask && p.mask[tok0 + k] == 0) bias = -1e30f;     // HF adds finfo.min to masked keys
+        sBias[k] = bias;
+    }
+    __syncthreads();
+
+    const int qi = lane & 15, g = lane >> 4;
+    const int nqt = (ntok + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + qi;
+        const int qc = q < ntok ? q : ntok - 1;
+        f16x8 qf[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *reinterpret_cast<const f16x8*>(base_hi + (int64_t)qc * D3 + h * HD + ks * 32 + g * 8);
+            if (SPLIT) ql[ks] = *reinterpret_cast<const f16x8*>(base_lo + (int64_t)qc * D3 + h * HD + ks * 32 + g * 8);
+        }
+        // The K / V^T fragment reads do not depend on the query tile; without the compiler barriers
+        // below LICM hoists ALL of them out of the qt loop (hundreds of VGPRs -> scratch spills).
+        // Each loop is software-pipelined one step deep by hand instead.
+#define KEEP_MEM_BARRIER() asm volatile("" ::: "memory")
+        KEEP_MEM_BARRIER();
+        f32x4 s[NT];
+        f16x8 kf[2][2], kl[2][2];
+        auto load_k = [&](int kt, int slot) {
+            const int row = kt * 16 + qi;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int off = row * HD + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
+                kf[slot][ks] = *reinterpret_cast<const f16x8*>(sK + off);
+                if (SPLIT) kl[slot][ks] = *reinterpret_cast<const f16x8*>(sKl + off);
+            }
+        };
+        load_k(0, 0);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt + 1 < NT) load_k(kt + 1, (kt + 1) & 1);
+            KEEP_MEM_BARRIER();
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (SPLIT) {
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt & 1][ks], ql[ks], s[kt], 0, 0, 0);
+                }
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        // ---- softmax over keys (registers + lanes {l, l^16, l^32, l^48})
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + kt * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] = s[kt][r] * p.scale + bias[r];
+                mx = fmaxf(mx, s[kt][r]);
+            }
+            if ((kt & 3) == 3) KEEP_MEM_BARRIER();
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T = V^T P^T
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f16x4 va[2][4][2], vb[2][4][2];      // [slot][dt][half]  hi / lo planes
+        auto load_v = [&](int u, int slot) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int voff = (dt * 16 + qi) * VS + 32 * u + g * 4;
+                va[slot][dt][0] = *reinterpret_cast<const f16x4*>(sVt + voff);
+                va[slot][dt][1] = *reinterpret_cast<const f16x4*>(sVt + voff + 16);
+                if (SPLIT) {
+                    vb[slot][dt][0] = *reinterpret_cast<const f16x4*>(sVtl + voff);
+                    vb[slot][dt][1] = *reinterpret_cast<const f16x4*>(sVtl + voff + 16);
+                }
+            }
+        };
+        KEEP_MEM_BARRIER();
+        load_v(0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + 1 < NU) load_v(u + 1, (u + 1) & 1);
+            KEEP_MEM_BARRIER();
+            f16x8 ph, pl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a0 = s[2 * u][r];
+                const float a1 = (2 * u + 1 < NT) ? s[(2 * u + 1 < NT) ? 2 * u + 1 : 0][r] : 0.f;
+                f16 h0, l0, h1, l1;
+                split_f16(a0, h0, l0); split_f16(a1, h1, l1);
+                ph[r] = h0; ph[4 + r] = h1; pl[r] = l0; pl[4 + r] = l1;
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f16x4 v0 = va[u & 1][dt][0], v1 = va[u & 1][dt][1];
+                const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (SPLIT) {
+                    const f16x4 w0 = vb[u & 1][dt][0], w1 = vb[u & 1][dt][1];
+                    const f16x8 vl = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pl, o[dt], 0, 0, 0);
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph, o[dt], 0, 0, 0);
+            }
+        }
+#undef KEEP_MEM_BARRIER
+        if (q < ntok) {
+            const int64_t orow = (tok0 + q) * D + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 oh, ol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f16 hh, ll; split_f16(o[dt][r] * inv, hh, ll); oh[r] = hh; ol[r] = ll; }
+                *reinterpret_cast<f16x4*>(p.out_hi + orow + dt * 16 + g * 4) = oh;
+                if (SPLIT) *reinterpret_cast<f16x4*>(p.out_lo + orow + dt * 16 + g * 4) = ol;
+            }
+        }
+    }
+}
+
+template <int NT, bool SPLIT>
+int launch_one(const AttnParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t bytes = att_lds_bytes(NT, SPLIT);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NT, SPLIT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -2;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<NT, SPLIT>), dim3(p.batch * p.heads), dim3(ATT_THREADS), bytes, s, p);
+    return 0;
+}
+
+}  // namespace keepk
+
+int launch_attention(const AttnParams& p, hipStream_t s) {
+    using namespace keepk;
+    const int nt = (p.ntok + 15) / 16;
+    if (p.ntok < 1 || p.batch < 1) return -1;
+    if (p.split) {
+        if (nt <= 4) return launch_one<4, true>(p, s);
+        if (nt <= 8) return launch_one<8, true>(p, s);
+        if (nt <= 13) return launch_one<13, true>(p, s);
+        if (nt <= 16) return launch_one<16, true>(p, s);
+        return -1;
+    }
+    if (nt <= 4) return launch_one<4, false>(p, s);
+    if (nt <= 8) return launch_one<8, false>(p, s);
+    if (nt <= 13) return launch_one<13, false>(p, s);
+    if (nt <= 16) return launch_one<16, false>(p, s);
+    if (nt <= 32) return launch_one<32, false>(p, s);
+    return -1;
+}

@@ -1,0 +1,123 @@
+// Shared device/host helpers for libkeep_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KEEP_WAVE 64
+
+// fp16 has 65504 as its largest finite value: saturate instead of producing inf
+// (ViT residual streams can carry outlier channels; the stream itself stays fp32).
+__device__ __forceinline__ f16 to_f16_sat(float x) {
+    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    return (f16)x;
+}
+
+// hi/lo split used by the "strict" (3-pass) precision mode: x ~= hi + lo with
+// hi = fp16(x), lo = fp16(x - hi).  |x - hi - lo| <= 2^-22 |x| (2^-25 abs floor).
+__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
+    hi = to_f16_sat(x);
+    lo = (f16)(x - (float)hi);
+}
+
+// Exact (erf) GELU: timm nn.GELU and HF hidden_act="gelu".
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Kernel launch parameter blocks (plain structs, passed by value)
+// ---------------------------------------------------------------------------
+
+// Epilogue selector of the fp16 MFMA GEMM  C[m][n] = sum_k A[m][k] W[n][k].
+enum GemmEpi : int {
+    EPI_F16      = 0,   // out_f16 = acc + bias                                   (QKV)
+    EPI_GELU_F16 = 1,   // out_f16 = gelu(acc + bias)                             (fc1)
+    EPI_RESID_LS = 2,   // resid  += ls[n] * (acc + bias)   fp32, in place        (proj / fc2, ViT)
+    EPI_PATCH    = 3,   // resid[b*197+1+p] = acc + bias + pos[1+p]               (patch embed)
+    EPI_RESID_F32= 4,   // out_f32 = acc + bias + resid      (BERT pre-LN sum; may alias resid)
+};
+
+struct GemmParams {
+    const f16* a_hi; const f16* a_lo;     // [M][K] activations (lo plane only when nseg==3)
+    const f16* w_hi; const f16* w_lo;     // [N][K] weights
+    int M, N, K;                          // K = per-segment depth; multiples: N%128==0, K%64==0
+    int nseg;                             // 1: A_hi*W_hi ; 3: A_hi*W_hi + A_lo*W_hi + A_hi*W_lo
+    const float* bias;                    // [N]
+    const float* ls;                      // [N]   (EPI_RESID_LS)
+    const float* pos;                     // [197][N] (EPI_PATCH)
+    float* resid;                         // fp32 [M'][N]
+    float* out_f32;                       // EPI_RESID_F32
+    f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
+    int patches_per_img;                  // EPI_PATCH: 196
+};
+
+void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);
+
+// Attention over a fused [M][3*D] qkv buffer (token-major; q|k|v, head-major inside each).
+struct AttnParams {
+    const f16* qkv_hi; const f16* qkv_lo; // lo only in split mode
+    f16* out_hi; f16* out_lo;             // [M][D]
+    const int64_t* mask;                  // [batch][ntok] (1 = attend) or nullptr
+    int batch, ntok, heads;               // head_dim fixed at 64
+    int split;                            // 0/1
+    float scale;                          // 1/sqrt(64)
+};
+int launch_attention(const AttnParams& p, hipStream_t s);   // returns 0 or -1 (unsupported ntok)
+
+// LayerNorm over rows of D in {768,1024}; fp32 in, fp16 (hi[,lo]) and/or fp32 out.
+struct LnParams {
+    const float* x; int64_t x_stride;     // row stride in elements
+    const float* add;                     // optional second addend (same stride as x)   [unused when null]
+    const float* gamma; const float* beta;
+    int rows, D; float eps;
+    f16* out_hi; f16* out_lo;             // [rows][D] dense (nullable)
+    float* out_f32; int64_t out_f32_stride;   // nullable
+};
+int launch_layernorm(const LnParams& p, hipStream_t s);
+
+// fp32 "NT" GEMM on the f32 MFMA: out[m][n] = act(scale * sum_k A[m][k] B[n][k] + bias[n])
+enum SgemmAct : int { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2 };
+struct SgemmParams {
+    const float* a; int64_t lda;
+    const float* b; int64_t ldb;
+    float* out; int64_t ldo;
+    const float* bias;                    // nullable
+    int M, N, K;                          // K % 16 == 0
+    float scale; int act;
+};
+int launch_sgemm_f32(const SgemmParams& p, hipStream_t s);
+
+// Row-wise helpers (rowops.hip)
+void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_lo,
+                   const float* cls, const float* pos, float* resid, int D, hipStream_t s);
+void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s);
+void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s);
+void launch_row_argmax(const float* x, int rows, int cols, int32_t* out, hipStream_t s);
+void launch_row_softmax(const float* x, int rows, int cols, float scale, float* out, hipStream_t s);
+void launch_row_softmax_f16(const float* x, int rows, int cols, float scale, f16* out, hipStream_t s);
+void launch_top2_score(const float* x, int rows, int cols, float* partial, float* out, hipStream_t s);
+void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const float* wemb, const float* pemb,
+                          const float* temb, const float* gamma, const float* beta, float eps,
+                          int P, int T, int D, int vocab, int type_vocab,
+                          float* resid, f16* out_hi, f16* out_lo, int* err_flag, hipStream_t s);
+void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s);
+
+enum PixelDType : int { PIX_F32 = 0, PIX_F16 = 1, PIX_BF16 = 2 };

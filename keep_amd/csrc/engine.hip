@@ -1,0 +1,904 @@
+// Host side of libkeep_hip: handle, weight store (release state_dict key layout), workspace arena,
+// tower orchestration and the extern "C" boundary declared in include/keep_hip.h.
+//
+// Orchestration mirrors the reference's call order, not its code:
+//   encode_image  quick_start/keep_inference.py:54-58  -> timm VisionTransformer.forward
+//   encode_text   quick_start/keep_inference.py:60-62  -> HF BertModel.forward           
+#include "common.h"
+#include "../../include/keep_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define HIPCHK(h, expr)                                                                      \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) return (h)->fail(KEEP_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+struct WTensor {
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+    float* f32 = nullptr;     // kept for vectors / embeddings / head / pooler
+    f16* hi = nullptr;        // GEMM weights: fp16 planes
+    f16* lo = nullptr;
+};
+
+enum Tag {
+    T_VIT_IM2COL, T_VIT_PATCH, T_VIT_LN, T_VIT_QKV, T_VIT_ATTN, T_VIT_PROJ, T_VIT_FC1, T_VIT_FC2, T_VIT_HEAD,
+    T_TXT_EMBED, T_TXT_LN, T_TXT_QKV, T_TXT_ATTN, T_TXT_OUT, T_TXT_FFN1, T_TXT_FFN2, T_TXT_POOL, T_SIM, T_COUNT
+};
+const char* kTagNames[T_COUNT] = {
+    "vit.im2col", "vit.patch", "vit.ln", "vit.qkv", "vit.attn", "vit.proj", "vit.fc1", "vit.fc2", "vit.head",
+    "text.embed", "text.ln", "text.qkv", "text.attn", "text.out", "text.ffn1", "text.ffn2", "text.pool", "sim"};
+
+struct VitBlock {
+    const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b, *ls1, *ls2;
+    const WTensor *qkv, *proj, *fc1, *fc2;
+};
+struct BertLayer {
+    WTensor qkv;                 // fused [3H, H]
+    float* qkv_b = nullptr;      // fused [3H]
+    const float *o_b, *ln1w, *ln1b, *i_b, *d_b, *ln2w, *ln2b;
+    const WTensor *o, *i, *d;
+};
+
+}  // namespace
+
+struct keep_handle {
+    int device = 0;
+    std::string err;
+    std::map<std::string, WTensor> w;
+    bool finalized = false;
+
+    // dims (filled at finalize)
+    int vit_depth = 0, vit_D = 0, vit_heads = 0, vit_F = 0, proj_dim = 0;
+    int bert_layers = 0, bert_H = 0, bert_heads = 0, bert_F = 0, bert_vocab = 0, bert_maxpos = 0, bert_types = 0;
+    std::vector<VitBlock> vblocks;
+    std::vector<BertLayer> blayers;
+
+    // options
+    int precision = KEEP_PREC_FP16;
+    int strict_blocks = 0;
+    int max_tiles = 256;
+    int max_prompts = 64;
+
+    // workspace arena
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    int* err_flag = nullptr;     // device int: out-of-range token ids
+
+    // profiling
+    int prof_mode = 0;           // 0 off, 1 single tag, 2 all
+    int prof_tag = -1;
+    struct Rec { hipEvent_t a, b; int tag; };
+    std::vector<Rec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double prof_ms[T_COUNT] = {0};
+    int64_t prof_n[T_COUNT] = {0};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[1024];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+    bool split_layer(int i) const { return precision == KEEP_PREC_STRICT || i < strict_blocks; }
+    bool any_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
+
+    bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && tag == prof_tag); }
+    void prof_begin(int tag, hipStream_t s) {
+        if (!prof_on(tag)) return;
+        Rec r; r.tag = tag;
+        if (!pool.empty()) { r.a = pool.back().first; r.b = pool.back().second; pool.pop_back(); }
+        else { hipEventCreate(&r.a); hipEventCreate(&r.b); }
+        hipEventRecord(r.a, s);
+        recs.push_back(r);
+    }
+    void prof_end(int tag, hipStream_t s) {
+        if (!prof_on(tag)) return;
+        hipEventRecord(recs.back().b, s);
+    }
+    void prof_collect() {
+        for (auto& r : recs) {
+            hipEventSynchronize(r.b);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, r.a, r.b);
+            prof_ms[r.tag] += ms; prof_n[r.tag] += 1;
+            pool.push_back({r.a, r.b});
+        }
+        recs.clear();
+    }
+};
+
+namespace {
+
+struct Scope {     // RAII profile bracket
+    keep_handle* h; int tag; hipStream_t s;
+    Scope(keep_handle* h_, int t, hipStream_t s_) : h(h_), tag(t), s(s_) { h->prof_begin(tag, s); }
+    ~Scope() { h->prof_end(tag, s); }
+};
+
+bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 0; }
+bool ends_with(const std::string& s, const char* p) {
+    const size_t n = strlen(p);
+    return s.size() >= n && s.compare(s.size() - n, n, p) == 0;
+}
+
+// GEMM weights are stored as fp16 planes only; everything else keeps fp32.
+bool is_gemm_weight(const std::string& k) {
+    if (k == "visual.patch_embed.proj.weight") return true;
+    if (starts_with(k, "visual.blocks.") && ends_with(k, ".weight") &&
+        (k.find(".attn.qkv.") != std::string::npos || k.find(".attn.proj.") != std::string::npos ||
+         k.find(".mlp.fc1.") != std::string::npos || k.find(".mlp.fc2.") != std::string::npos)) return true;
+    if (starts_with(k, "text.encoder.layer.") && ends_with(k, ".weight") && k.find("LayerNorm") == std::string::npos) return true;
+    return false;
+}
+
+int64_t numel_of(const std::vector<int64_t>& s) { int64_t n = 1; for (auto d : s) n *= d; return n; }
+
+const WTensor* find(keep_handle* h, const std::string& k) {
+    auto it = h->w.find(k);
+    return it == h->w.end() ? nullptr : &it->second;
+}
+
+bool shape_is(const WTensor* t, std::initializer_list<int64_t> s) {
+    if (!t || t->shape.size() != s.size()) return false;
+    size_t i = 0;
+    for (auto d : s) if (t->shape[i++] != d) return false;
+    return true;
+}
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    template <typename T> T* take(size_t n) { T* p = reinterpret_cast<T*>(base + off); off += align_up(n * sizeof(T)); return p; }
+};
+
+struct VitWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo, *pat_hi, *pat_lo; float *cls, *h1; };
+struct TxtWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; };
+
+size_t vit_ws_bytes(const keep_handle* h, int64_t Bc, bool split) {
+    const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F, k = split ? 2 : 1;
+    return align_up(M * D * 4) + k * (align_up(M * D * 2) * 2 + align_up(M * 3 * D * 2) + align_up(M * F * 2)) + 2 * align_up(Mp * 768 * 2) +
+           align_up((size_t)Bc * D * 4) + align_up((size_t)Bc * h->proj_dim * 4) + 4096;
+}
+VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
+    const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F;
+    Carver c(arena); VitWs w{};
+    w.resid = c.take<float>(M * D);
+    w.xn_hi = c.take<f16>(M * D);      w.xn_lo = split ? c.take<f16>(M * D) : nullptr;
+    w.qkv_hi = c.take<f16>(M * 3 * D); w.qkv_lo = split ? c.take<f16>(M * 3 * D) : nullptr;
+    w.att_hi = c.take<f16>(M * D);     w.att_lo = split ? c.take<f16>(M * D) : nullptr;
+    w.mlp_hi = c.take<f16>(M * F);     w.mlp_lo = split ? c.take<f16>(M * F) : nullptr;
+    w.pat_hi = c.take<f16>(Mp * 768);  w.pat_lo = c.take<f16>(Mp * 768);
+    w.cls = c.take<float>((size_t)Bc * D);
+    w.h1 = c.take<float>((size_t)Bc * h->proj_dim);
+    return w;
+}
+size_t txt_ws_bytes(const keep_handle* h, int64_t Pc, int64_t T, bool split) {
+    const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F, k = split ? 2 : 1;
+    return align_up(M * H * 4) + k * (align_up(M * H * 2) * 2 + align_up(M * 3 * H * 2) + align_up(M * F * 2)) + 4096;
+}
+TxtWs carve_txt(const keep_handle* h, char* arena, int64_t Pc, int64_t T, bool split) {
+    const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F;
+    Carver c(arena); TxtWs w{};
+    w.resid = c.take<float>(M * H);
+    w.xn_hi = c.take<f16>(M * H);      w.xn_lo = split ? c.take<f16>(M * H) : nullptr;
+    w.qkv_hi = c.take<f16>(M * 3 * H); w.qkv_lo = split ? c.take<f16>(M * 3 * H) : nullptr;
+    w.att_hi = c.take<f16>(M * H);     w.att_lo = split ? c.take<f16>(M * H) : nullptr;
+    w.mlp_hi = c.take<f16>(M * F);     w.mlp_lo = split ? c.take<f16>(M * F) : nullptr;
+    return w;
+}
+
+int ensure_arena(keep_handle* h, size_t bytes) {
+    if (bytes <= h->arena_bytes) return KEEP_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->arena) HIPCHK(h, hipFree(h->arena));
+    h->arena = nullptr; h->arena_bytes = 0;
+    HIPCHK(h, hipMalloc(&h->arena, bytes));
+    h->arena_bytes = bytes;
+    return KEEP_OK;
+}
+
+int check_launch(keep_handle* h, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return h->fail(KEEP_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return KEEP_OK;
+}
+
+GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M, bool split, const float* bias) {
+    GemmParams p{};
+    p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w->hi; p.w_lo = w->lo;
+    p.M = M; p.N = (int)w->shape[0]; p.K = (int)(w->numel / w->shape[0]);
+    p.nseg = split ? 3 : 1;
+    p.bias = bias;
+    p.patches_per_img = 196;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+int vit_chunk(keep_handle* h, const void* pixels, int pix_dtype, int Bc, float* out, hipStream_t s) {
+    const bool any_split = h->any_split();
+    const int D = h->vit_D, M = Bc * 197;
+    VitWs ws = carve_vit(h, h->arena, Bc, any_split);
+    // The patch embed is 0.25 % of the FLOPs but its rounding error feeds all 24 blocks: always run it
+    // as the hi/lo split product.
+    const bool sp0 = true;
+    {
+        Scope sc(h, T_VIT_IM2COL, s);
+        launch_im2col(pixels, pix_dtype, Bc, ws.pat_hi, sp0 ? ws.pat_lo : nullptr,
+                      find(h, "visual.cls_token")->f32, find(h, "visual.pos_embed")->f32, ws.resid, D, s);
+    }
+    {
+        Scope sc(h, T_VIT_PATCH, s);
+        GemmParams p = gemm_params(ws.pat_hi, ws.pat_lo, find(h, "visual.patch_embed.proj.weight"), Bc * 196, sp0,
+                                   find(h, "visual.patch_embed.proj.bias")->f32);
+        p.pos = find(h, "visual.pos_embed")->f32;
+        p.resid = ws.resid;
+        launch_gemm_f16(p, EPI_PATCH, s);
+    }
+    for (int i = 0; i < h->vit_depth; ++i) {
+        const VitBlock& b = h->vblocks[i];
+        const bool sp = h->split_layer(i);
+        LnParams ln{};
+        ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
+        ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr;
+        {
+            Scope sc(h, T_VIT_LN, s);
+            ln.gamma = b.n1w; ln.beta = b.n1b;
+            if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
+        }
+        {
+            Scope sc(h, T_VIT_QKV, s);
+            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
+            p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
+            launch_gemm_f16(p, EPI_F16, s);
+        }
+        {
+            Scope sc(h, T_VIT_ATTN, s);
+            AttnParams a{};
+            a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
+            a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f;
+            if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
+        }
+        {
+            Scope sc(h, T_VIT_PROJ, s);
+            GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.proj, M, sp, b.proj_b);
+            p.ls = b.ls1; p.resid = ws.resid;
+            launch_gemm_f16(p, EPI_RESID_LS, s);
+        }
+        {
+            Scope sc(h, T_VIT_LN, s);
+            ln.gamma = b.n2w; ln.beta = b.n2b;
+            launch_layernorm(ln, s);
+        }
+        {
+            Scope sc(h, T_VIT_FC1, s);
+            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.fc1, M, sp, b.fc1_b);
+            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr;
+            launch_gemm_f16(p, EPI_GELU_F16, s);
+        }
+        {
+            Scope sc(h, T_VIT_FC2, s);
+            GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.fc2, M, sp, b.fc2_b);
+            p.ls = b.ls2; p.resid = ws.resid;
+            launch_gemm_f16(p, EPI_RESID_LS, s);
+        }
+    }
+    {
+        // final LayerNorm is per-token, global_pool='token' reads row 0 only -> normalise CLS rows only
+        Scope sc(h, T_VIT_HEAD, s);
+        LnParams ln{};
+        ln.x = ws.resid; ln.x_stride = (int64_t)197 * D; ln.rows = Bc; ln.D = D; ln.eps = 1e-6f;
+        ln.gamma = find(h, "visual.norm.weight")->f32; ln.beta = find(h, "visual.norm.bias")->f32;
+        ln.out_f32 = ws.cls; ln.out_f32_stride = D;
+        launch_layernorm(ln, s);
+        const WTensor* w0 = find(h, "visual_head.0.weight");
+        const WTensor* w2 = find(h, "visual_head.2.weight");
+        SgemmParams g{};
+        g.a = ws.cls; g.lda = D; g.b = w0->f32; g.ldb = D; g.out = ws.h1; g.ldo = h->proj_dim;
+        g.bias = find(h, "visual_head.0.bias")->f32; g.M = Bc; g.N = h->proj_dim; g.K = D; g.scale = 1.f; g.act = ACT_GELU;
+        if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "visual_head.0 shape");
+        g.a = ws.h1; g.lda = h->proj_dim; g.b = w2->f32; g.ldb = h->proj_dim; g.out = out; g.ldo = h->proj_dim;
+        g.bias = find(h, "visual_head.2.bias")->f32; g.K = h->proj_dim; g.act = ACT_NONE;
+        if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "visual_head.2 shape");
+        launch_l2norm_rows(out, Bc, h->proj_dim, 1e-12f, s);
+    }
+    return check_launch(h, "encode_image");
+}
+
+int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const int64_t* mask, int Pc, int T,
+              float* out, hipStream_t s) {
+    const bool any_split = h->any_split();
+    const int H = h->bert_H, M = Pc * T;
+    TxtWs ws = carve_txt(h, h->arena, Pc, T, any_split);
+    {
+        Scope sc(h, T_TXT_EMBED, s);
+        launch_bert_embed_ln(ids, types, find(h, "text.embeddings.word_embeddings.weight")->f32,
+                             find(h, "text.embeddings.position_embeddings.weight")->f32,
+                             find(h, "text.embeddings.token_type_embeddings.weight")->f32,
+                             find(h, "text.embeddings.LayerNorm.weight")->f32,
+                             find(h, "text.embeddings.LayerNorm.bias")->f32, 1e-12f, Pc, T, H, h->bert_vocab,
+                             h->bert_types, ws.resid, ws.xn_hi, any_split ? ws.xn_lo : nullptr, h->err_flag, s);
+    }
+    for (int l = 0; l < h->bert_layers; ++l) {
+        const BertLayer& b = h->blayers[l];
+        const bool sp = h->split_layer(l);
+        const bool sp_next = (l + 1 < h->bert_layers) && h->split_layer(l + 1);
+        {
+            Scope sc(h, T_TXT_QKV, s);
+            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
+            p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
+            launch_gemm_f16(p, EPI_F16, s);
+        }
+        {
+            Scope sc(h, T_TXT_ATTN, s);
+            AttnParams a{};
+            a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
+            a.mask = mask; a.batch = Pc; a.ntok = T; a.heads = h->bert_heads; a.split = sp; a.scale = 0.125f;
+            if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %d unsupported%s", T,
+                                                       sp ? " in strict mode (max 256)" : " (max 512)");
+        }
+        {
+            Scope sc(h, T_TXT_OUT, s);
+            GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.o, M, sp, b.o_b);
+            p.resid = ws.resid; p.out_f32 = ws.resid;
+            launch_gemm_f16(p, EPI_RESID_F32, s);
+        }
+        LnParams ln{};
+        ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
+        ln.out_f32 = ws.resid; ln.out_f32_stride = H; ln.out_hi = ws.xn_hi;
+        {
+            Scope sc(h, T_TXT_LN, s);
+            ln.gamma = b.ln1w; ln.beta = b.ln1b; ln.out_lo = sp ? ws.xn_lo : nullptr;
+            if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", H);
+        }
+        {
+            Scope sc(h, T_TXT_FFN1, s);
+            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
+            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr;
+            launch_gemm_f16(p, EPI_GELU_F16, s);
+        }
+        {
+            Scope sc(h, T_TXT_FFN2, s);
+            GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.d, M, sp, b.d_b);
+            p.resid = ws.resid; p.out_f32 = ws.resid;
+            launch_gemm_f16(p, EPI_RESID_F32, s);
+        }
+        {
+            Scope sc(h, T_TXT_LN, s);
+            ln.gamma = b.ln2w; ln.beta = b.ln2b; ln.out_lo = sp_next ? ws.xn_lo : nullptr;
+            launch_layernorm(ln, s);
+        }
+    }
+    {
+        Scope sc(h, T_TXT_POOL, s);
+        SgemmParams g{};
+        g.a = ws.resid; g.lda = (int64_t)T * H;            // row p*T: the [CLS] token of prompt p
+        g.b = find(h, "text.pooler.dense.weight")->f32; g.ldb = H; g.out = out; g.ldo = H;
+        g.bias = find(h, "text.pooler.dense.bias")->f32; g.M = Pc; g.N = H; g.K = H; g.scale = 1.f; g.act = ACT_TANH;
+        if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "pooler shape");
+        launch_l2norm_rows(out, Pc, H, 1e-12f, s);
+    }
+    return check_launch(h, "encode_text");
+}
+
+// store one state_dict entry
+int store_tensor(keep_handle* h, const std::string& key, const float* dev, const std::vector<int64_t>& shape) {
+    WTensor t; t.shape = shape; t.numel = numel_of(shape);
+    if (t.numel <= 0) return h->fail(KEEP_EINVAL, "%s: empty tensor", key.c_str());
+    if (is_gemm_weight(key)) {
+        HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
+        HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
+        launch_split_f16(dev, t.hi, t.lo, t.numel, nullptr);
+        HIPCHK(h, hipStreamSynchronize(nullptr));
+    } else {
+        const size_t bytes = (size_t)(t.numel > 4 ? t.numel : 4) * sizeof(float);
+        HIPCHK(h, hipMalloc(&t.f32, bytes));
+        HIPCHK(h, hipMemcpy(t.f32, dev, t.numel * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    auto it = h->w.find(key);
+    if (it != h->w.end()) {
+        if (it->second.f32) hipFree(it->second.f32);
+        if (it->second.hi) hipFree(it->second.hi);
+        if (it->second.lo) hipFree(it->second.lo);
+    }
+    h->w[key] = t;
+    h->finalized = false;
+    return KEEP_OK;
+}
+
+const float* need_vec(keep_handle* h, const std::string& key, int64_t n, std::string& missing) {
+    const WTensor* t = find(h, key);
+    if (!t || !t->f32 || t->numel != n) { missing += (missing.empty() ? "" : ", ") + key; return nullptr; }
+    return t->f32;
+}
+const WTensor* need_mat(keep_handle* h, const std::string& key, int64_t n, int64_t k, std::string& missing) {
+    const WTensor* t = find(h, key);
+    if (!t || !t->hi || t->shape.empty() || t->shape[0] != n || t->numel != n * k) {
+        missing += (missing.empty() ? "" : ", ") + key; return nullptr;
+    }
+    return t;
+}
+
+int finalize_vit(keep_handle* h) {
+    h->vblocks.clear(); h->vit_depth = 0;
+    const WTensor* pe = find(h, "visual.patch_embed.proj.weight");
+    if (!pe) {
+        for (auto& kv : h->w) if (starts_with(kv.first, "visual")) return h->fail(KEEP_EKEY, "missing key visual.patch_embed.proj.weight");
+        return KEEP_OK;     // image tower not loaded
+    }
+    if (pe->shape.size() != 4 || pe->shape[1] != 3 || pe->shape[2] != 16 || pe->shape[3] != 16)
+        return h->fail(KEEP_EUNSUPPORTED, "patch_embed.proj.weight must be [D,3,16,16]");
+    const int64_t D = pe->shape[0];
+    if (D % 256 || D > 1024) return h->fail(KEEP_EUNSUPPORTED, "embed dim %lld unsupported", (long long)D);
+    int depth = 0;
+    while (find(h, "visual.blocks." + std::to_string(depth) + ".attn.qkv.weight")) ++depth;
+    if (!depth) return h->fail(KEEP_EKEY, "missing key visual.blocks.0.attn.qkv.weight");
+    const WTensor* fc1 = find(h, "visual.blocks.0.mlp.fc1.weight");
+    if (!fc1) return h->fail(KEEP_EKEY, "missing key visual.blocks.0.mlp.fc1.weight");
+    const int64_t F = fc1->shape[0];
+    const WTensor* h0 = find(h, "visual_head.0.weight");
+    if (!h0 || h0->shape.size() != 2 || h0->shape[1] != D) return h->fail(KEEP_EKEY, "missing or mis-shaped key visual_head.0.weight");
+    const int64_t PJ = h0->shape[0];
+    std::string miss;
+    need_vec(h, "visual.cls_token", D, miss);
+    need_vec(h, "visual.pos_embed", 197 * D, miss);
+    need_vec(h, "visual.patch_embed.proj.bias", D, miss);
+    need_vec(h, "visual.norm.weight", D, miss);
+    need_vec(h, "visual.norm.bias", D, miss);
+    need_vec(h, "visual_head.0.bias", PJ, miss);
+    need_vec(h, "visual_head.2.weight", PJ * PJ, miss);
+    need_vec(h, "visual_head.2.bias", PJ, miss);
+    for (int i = 0; i < depth; ++i) {
+        const std::string p = "visual.blocks." + std::to_string(i) + ".";
+        VitBlock b{};
+        b.n1w = need_vec(h, p + "norm1.weight", D, miss); b.n1b = need_vec(h, p + "norm1.bias", D, miss);
+        b.n2w = need_vec(h, p + "norm2.weight", D, miss); b.n2b = need_vec(h, p + "norm2.bias", D, miss);
+        b.qkv = need_mat(h, p + "attn.qkv.weight", 3 * D, D, miss); b.qkv_b = need_vec(h, p + "attn.qkv.bias", 3 * D, miss);
+        b.proj = need_mat(h, p + "attn.proj.weight", D, D, miss);   b.proj_b = need_vec(h, p + "attn.proj.bias", D, miss);
+        b.fc1 = need_mat(h, p + "mlp.fc1.weight", F, D, miss);      b.fc1_b = need_vec(h, p + "mlp.fc1.bias", F, miss);
+        b.fc2 = need_mat(h, p + "mlp.fc2.weight", D, F, miss);      b.fc2_b = need_vec(h, p + "mlp.fc2.bias", D, miss);
+        b.ls1 = need_vec(h, p + "ls1.gamma", D, miss);              b.ls2 = need_vec(h, p + "ls2.gamma", D, miss);
+        h->vblocks.push_back(b);
+    }
+    if (!miss.empty()) return h->fail(KEEP_EKEY, "missing or mis-shaped key(s): %s", miss.c_str());
+    if (F % 128 || D % 128 || PJ % 16) return h->fail(KEEP_EUNSUPPORTED, "ViT dims not tileable");
+    h->vit_depth = depth; h->vit_D = (int)D; h->vit_heads = (int)(D / 64); h->vit_F = (int)F; h->proj_dim = (int)PJ;
+    return KEEP_OK;
+}
+
+int finalize_bert(keep_handle* h) {
+    for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
+    h->blayers.clear(); h->bert_layers = 0;
+    const WTensor* we = find(h, "text.embeddings.word_embeddings.weight");
+    if (!we) {
+        for (auto& kv : h->w) if (starts_with(kv.first, "text.")) return h->fail(KEEP_EKEY, "missing key text.embeddings.word_embeddings.weight");
+        return KEEP_OK;
+    }
+    if (we->shape.size() != 2) return h->fail(KEEP_EINVAL, "word_embeddings must be 2-D");
+    const int64_t V = we->shape[0], H = we->shape[1];
+    if (H != 768 && H != 1024) return h->fail(KEEP_EUNSUPPORTED, "hidden size %lld unsupported (768 or 1024)", (long long)H);
+    int L = 0;
+    while (find(h, "text.encoder.layer." + std::to_string(L) + ".attention.self.query.weight")) ++L;
+    if (!L) return h->fail(KEEP_EKEY, "missing key text.encoder.layer.0.attention.self.query.weight");
+    const WTensor* iw = find(h, "text.encoder.layer.0.intermediate.dense.weight");
+    if (!iw) return h->fail(KEEP_EKEY, "missing key text.encoder.layer.0.intermediate.dense.weight");
+    const int64_t F = iw->shape[0];
+    const WTensor* pos = find(h, "text.embeddings.position_embeddings.weight");
+    const WTensor* typ = find(h, "text.embeddings.token_type_embeddings.weight");
+    if (!pos || !typ || pos->shape.size() != 2 || typ->shape.size() != 2 || pos->shape[1] != H || typ->shape[1] != H)
+        return h->fail(KEEP_EKEY, "missing or mis-shaped position/token_type embeddings");
+    std::string miss;
+    need_vec(h, "text.embeddings.LayerNorm.weight", H, miss);
+    need_vec(h, "text.embeddings.LayerNorm.bias", H, miss);
+    need_vec(h, "text.pooler.dense.weight", H * H, miss);
+    need_vec(h, "text.pooler.dense.bias", H, miss);
+    h->blayers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "text.encoder.layer." + std::to_string(l) + ".";
+        BertLayer& b = h->blayers[l];
+        const WTensor* q = need_mat(h, p + "attention.self.query.weight", H, H, miss);
+        const WTensor* k = need_mat(h, p + "attention.self.key.weight", H, H, miss);
+        const WTensor* v = need_mat(h, p + "attention.self.value.weight", H, H, miss);
+        const float* qb = need_vec(h, p + "attention.self.query.bias", H, miss);
+        const float* kb = need_vec(h, p + "attention.self.key.bias", H, miss);
+        const float* vb = need_vec(h, p + "attention.self.value.bias", H, miss);
+        b.o = need_mat(h, p + "attention.output.dense.weight", H, H, miss);
+        b.o_b = need_vec(h, p + "attention.output.dense.bias", H, miss);
+        b.ln1w = need_vec(h, p + "attention.output.LayerNorm.weight", H, miss);
+        b.ln1b = need_vec(h, p + "attention.output.LayerNorm.bias", H, miss);
+        b.i = need_mat(h, p + "intermediate.dense.weight", F, H, miss);
+        b.i_b = need_vec(h, p + "intermediate.dense.bias", F, miss);
+        b.d = need_mat(h, p + "output.dense.weight", H, F, miss);
+        b.d_b = need_vec(h, p + "output.dense.bias", H, miss);
+        b.ln2w = need_vec(h, p + "output.LayerNorm.weight", H, miss);
+        b.ln2b = need_vec(h, p + "output.LayerNorm.bias", H, miss);
+        if (!miss.empty()) continue;
+        // fuse q|k|v into one [3H,H] weight so the layer needs a single projection GEMM
+        b.qkv.shape = {3 * H, H}; b.qkv.numel = 3 * H * H;
+        HIPCHK(h, hipMalloc(&b.qkv.hi, b.qkv.numel * sizeof(f16)));
+        HIPCHK(h, hipMalloc(&b.qkv.lo, b.qkv.numel * sizeof(f16)));
+        HIPCHK(h, hipMalloc(&b.qkv_b, 3 * H * sizeof(float)));
+        const WTensor* parts[3] = {q, k, v};
+        const float* bparts[3] = {qb, kb, vb};
+        for (int j = 0; j < 3; ++j) {
+            HIPCHK(h, hipMemcpy(b.qkv.hi + (size_t)j * H * H, parts[j]->hi, H * H * sizeof(f16), hipMemcpyDeviceToDevice));
+            HIPCHK(h, hipMemcpy(b.qkv.lo + (size_t)j * H * H, parts[j]->lo, H * H * sizeof(f16), hipMemcpyDeviceToDevice));
+            HIPCHK(h, hipMemcpy(b.qkv_b + (size_t)j * H, bparts[j], H * sizeof(float), hipMemcpyDeviceToDevice));
+        }
+    }
+    if (!miss.empty()) { h->blayers.clear(); return h->fail(KEEP_EKEY, "missing or mis-shaped key(s): %s", miss.c_str()); }
+    if (F % 128 || H % 128) return h->fail(KEEP_EUNSUPPORTED, "BERT dims not tileable");
+    h->bert_layers = L; h->bert_H = (int)H; h->bert_heads = (int)(H / 64); h->bert_F = (int)F;
+    h->bert_vocab = (int)V; h->bert_maxpos = (int)pos->shape[0]; h->bert_types = (int)typ->shape[0];
+    return KEEP_OK;
+}
+
+bool known_key(const std::string& k) {
+    static const char* exact[] = {"logit_scale", "visual.cls_token", "visual.pos_embed", "visual.patch_embed.proj.weight",
+        "visual.patch_embed.proj.bias", "visual.norm.weight", "visual.norm.bias", "visual_head.0.weight", "visual_head.0.bias",
+        "visual_head.2.weight", "visual_head.2.bias", "text.embeddings.word_embeddings.weight",
+        "text.embeddings.position_embeddings.weight", "text.embeddings.token_type_embeddings.weight",
+        "text.embeddings.LayerNorm.weight", "text.embeddings.LayerNorm.bias", "text.pooler.dense.weight", "text.pooler.dense.bias"};
+    for (auto e : exact) if (k == e) return true;
+    static const char* vsuf[] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+        "ls1.gamma", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias", "ls2.gamma"};
+    static const char* tsuf[] = {"attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
+        "attention.self.key.bias", "attention.self.value.weight", "attention.self.value.bias", "attention.output.dense.weight",
+        "attention.output.dense.bias", "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+        "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight", "output.dense.bias",
+        "output.LayerNorm.weight", "output.LayerNorm.bias"};
+    auto layered = [&](const char* prefix, const char* const* suf, size_t n) {
+        if (!starts_with(k, prefix)) return false;
+        size_t i = strlen(prefix), j = i;
+        while (j < k.size() && k[j] >= '0' && k[j] <= '9') ++j;
+        if (j == i || j >= k.size() || k[j] != '.') return false;
+        const std::string rest = k.substr(j + 1);
+        for (size_t q = 0; q < n; ++q) if (rest == suf[q]) return true;
+        return false;
+    };
+    return layered("visual.blocks.", vsuf, sizeof vsuf / sizeof *vsuf) || layered("text.encoder.layer.", tsuf, sizeof tsuf / sizeof *tsuf);
+}
+
+int tag_by_name(const char* name) {
+    for (int i = 0; i < T_COUNT; ++i) if (!strcmp(name, kTagNames[i])) return i;
+    return -1;
+}
+
+// temp device buffers for the op entry points
+struct Tmp {
+    std::vector<void*> ptrs;
+    ~Tmp() { for (auto p : ptrs) hipFree(p); }
+    template <typename T> T* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(p); return (T*)p; }
+};
+
+__global__ void f16_planes_to_f32_kernel(const f16* hi, const f16* lo, float* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)hi[i] + (lo ? (float)lo[i] : 0.f);
+}
+void planes_to_f32(const f16* hi, const f16* lo, float* out, int64_t n, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f16_planes_to_f32_kernel, dim3(blocks), dim3(256), 0, s, hi, lo, out, n);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* keep_version(void) { return "keep_hip 0.1 (gfx950)"; }
+
+int keep_create(int device_id, keep_handle** out) {
+    if (!out) return KEEP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return KEEP_EHIP;
+    if (hipSetDevice(device_id) != hipSuccess) return KEEP_EHIP;
+    keep_handle* h = new keep_handle();
+    h->device = device_id;
+    if (hipMalloc(&h->err_flag, sizeof(int)) != hipSuccess) { delete h; return KEEP_ENOMEM; }
+    hipMemset(h->err_flag, 0, sizeof(int));
+    *out = h;
+    return KEEP_OK;
+}
+
+int keep_destroy(keep_handle* h) {
+    if (!h) return KEEP_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    h->prof_collect();
+    for (auto& e : h->pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo); }
+    for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
+    if (h->arena) hipFree(h->arena);
+    if (h->err_flag) hipFree(h->err_flag);
+    delete h;
+    return KEEP_OK;
+}
+
+const char* keep_last_error(keep_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndim, const int64_t* shape, int on_device) {
+    if (!h || !key || !data || ndim < 0 || ndim > 8) return KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const std::string k(key);
+    if (k == "text.embeddings.position_ids" || k == "text.embeddings.token_type_ids") return KEEP_OK;   // buffers of older checkpoints
+    if (!known_key(k)) return h->fail(KEEP_EKEY, "unexpected key %s", key);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (ndim == 0) shp = {1};
+    const int64_t n = numel_of(shp);
+    if (n <= 0) return h->fail(KEEP_EINVAL, "%s: bad shape", key);
+    if (on_device) return store_tensor(h, k, data, shp);
+    float* tmp = nullptr;
+    HIPCHK(h, hipMalloc(&tmp, n * sizeof(float)));
+    hipError_t e = hipMemcpy(tmp, data, n * sizeof(float), hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? store_tensor(h, k, tmp, shp) : h->fail(KEEP_EHIP, "H2D copy of %s failed", key);
+    hipFree(tmp);
+    return rc;
+}
+
+int keep_finalize_weights(keep_handle* h) {
+    if (!h) return KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = finalize_vit(h);
+    if (rc) return rc;
+    rc = finalize_bert(h);
+    if (rc) return rc;
+    if (!h->vit_depth && !h->bert_layers) return h->fail(KEEP_EKEY, "no tower loaded");
+    HIPCHK(h, hipDeviceSynchronize());
+    h->finalized = true;
+    return KEEP_OK;
+}
+
+int keep_vit_depth(keep_handle* h) { return h && h->finalized ? h->vit_depth : 0; }
+int keep_bert_layers(keep_handle* h) { return h && h->finalized ? h->bert_layers : 0; }
+
+int keep_set_option(keep_handle* h, const char* name, double value) {
+    if (!h || !name) return KEEP_EINVAL;
+    const std::string n(name);
+    const int v = (int)value;
+    if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
+    else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
+    else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
+    else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
+    else return h->fail(KEEP_EINVAL, "unknown option %s", name);
+    return KEEP_OK;
+}
+double keep_get_option(keep_handle* h, const char* name) {
+    if (!h || !name) return -1;
+    const std::string n(name);
+    if (n == "precision") return h->precision;
+    if (n == "strict_blocks") return h->strict_blocks;
+    if (n == "max_tiles") return h->max_tiles;
+    if (n == "max_prompts") return h->max_prompts;
+    return -1;
+}
+
+int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
+    if (!h || !h->finalized) return h ? h->fail(KEEP_ESTATE, "weights not finalised") : KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t need = 0;
+    if (tiles > 0 && h->vit_depth) {
+        const int64_t bc = tiles < h->max_tiles ? tiles : h->max_tiles;
+        need = vit_ws_bytes(h, bc, h->any_split());
+    }
+    if (prompts > 0 && seq > 0 && h->bert_layers) {
+        const int64_t pc = prompts < h->max_prompts ? prompts : h->max_prompts;
+        const size_t t = txt_ws_bytes(h, pc, seq, h->any_split());
+        need = t > need ? t : need;
+    }
+    return ensure_arena(h, need);
+}
+int64_t keep_workspace_bytes(keep_handle* h) { return h ? (int64_t)h->arena_bytes : 0; }
+
+int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, float* out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!h->finalized || !h->vit_depth) return h->fail(KEEP_ESTATE, "image tower not loaded / finalised");
+    if (!pixels || !out || B < 0) return h->fail(KEEP_EINVAL, "null pointer or negative batch");
+    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_BF16) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
+    if (B == 0) return KEEP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t bc_max = B < h->max_tiles ? B : h->max_tiles;
+    int rc = ensure_arena(h, vit_ws_bytes(h, bc_max, h->any_split()));
+    if (rc) return rc;
+    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : 2;
+    for (int64_t b0 = 0; b0 < B; b0 += bc_max) {
+        const int bc = (int)((B - b0) < bc_max ? (B - b0) : bc_max);
+        rc = vit_chunk(h, (const char*)pixels + (size_t)b0 * 3 * 224 * 224 * px, pix_dtype, bc, out + b0 * h->proj_dim, s);
+        if (rc) return rc;
+    }
+    return KEEP_OK;
+}
+
+int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, const int64_t* mask, int64_t P, int64_t T,
+                     float* out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!h->finalized || !h->bert_layers) return h->fail(KEEP_ESTATE, "text tower not loaded / finalised");
+    if (!ids || !out || P < 0 || T < 1) return h->fail(KEEP_EINVAL, "null pointer or bad shape");
+    if (T > h->bert_maxpos) return h->fail(KEEP_EINVAL, "sequence length %lld exceeds max_position_embeddings %d", (long long)T, h->bert_maxpos);
+    if (T > 512 || (h->any_split() && T > 256)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
+    if (P == 0) return KEEP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t pc_max = P < h->max_prompts ? P : h->max_prompts;
+    int rc = ensure_arena(h, txt_ws_bytes(h, pc_max, T, h->any_split()));
+    if (rc) return rc;
+    HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), s));
+    for (int64_t p0 = 0; p0 < P; p0 += pc_max) {
+        const int pc = (int)((P - p0) < pc_max ? (P - p0) : pc_max);
+        rc = txt_chunk(h, ids + p0 * T, types ? types + p0 * T : nullptr, mask ? mask + p0 * T : nullptr, pc, (int)T,
+                       out + p0 * h->bert_H, s);
+        if (rc) return rc;
+    }
+    return KEEP_OK;
+}
+
+int keep_token_error(keep_handle* h, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    return flag ? 1 : 0;
+}
+
+int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t N, int64_t P, int64_t D, float scale, int mode,
+                    void* out, int32_t* argmax_out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!img || !txt || N < 0 || P < 1 || D < 16 || D % 16) return h->fail(KEEP_EINVAL, "bad similarity arguments");
+    if (mode < KEEP_SIM_RAW || mode > KEEP_SIM_TOP2SCORE) return h->fail(KEEP_EINVAL, "similarity mode %d", mode);
+    if (mode == KEEP_SIM_ARGMAX && !argmax_out) return h->fail(KEEP_EINVAL, "argmax_out is null");
+    if (mode != KEEP_SIM_ARGMAX && !out) return h->fail(KEEP_EINVAL, "out is null");
+    if (N == 0) return KEEP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scope sc(h, T_SIM, s);
+    float* logits = (float*)out;
+    const bool need_tmp = (mode == KEEP_SIM_ARGMAX && !out) || mode == KEEP_SIM_SOFTMAX_F16 || mode == KEEP_SIM_TOP2SCORE;
+    const int nb = (int)((N + 255) / 256);
+    if (need_tmp) {
+        // scratch lives at the tail end of the arena so that a preceding encode on the same stream
+        // (which uses the front) is not disturbed; stream order serialises reuse.
+        const size_t bytes = align_up((size_t)N * P * 4) + align_up((size_t)nb * 4) + 256;
+        int rc = ensure_arena(h, bytes);
+        if (rc) return rc;
+        logits = (float*)h->arena;
+    }
+    SgemmParams g{};
+    g.a = img; g.lda = D; g.b = txt; g.ldb = D; g.out = logits; g.ldo = P; g.bias = nullptr;
+    g.M = (int)N; g.N = (int)P; g.K = (int)D; g.act = ACT_NONE;
+    g.scale = (mode == KEEP_SIM_RAW || mode == KEEP_SIM_ARGMAX) ? scale : 1.0f;
+    if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "similarity shape");
+    if (mode == KEEP_SIM_ARGMAX) launch_row_argmax(logits, (int)N, (int)P, argmax_out, s);
+    else if (mode == KEEP_SIM_SOFTMAX) launch_row_softmax(logits, (int)N, (int)P, scale, logits, s);
+    else if (mode == KEEP_SIM_SOFTMAX_F16) launch_row_softmax_f16(logits, (int)N, (int)P, scale, (f16*)out, s);
+    else if (mode == KEEP_SIM_TOP2SCORE) {
+        float* partial = (float*)(h->arena + align_up((size_t)N * P * 4));
+        launch_top2_score(logits, (int)N, (int)P, partial, (float*)out, s);
+    }
+    return check_launch(h, "similarity");
+}
+
+int keep_profile_enable(keep_handle* h, const char* tag) {
+    if (!h) return KEEP_EINVAL;
+    if (!tag) { h->prof_mode = 2; return KEEP_OK; }
+    if (!*tag) { h->prof_mode = 0; return KEEP_OK; }
+    const int t = tag_by_name(tag);
+    if (t < 0) return h->fail(KEEP_EINVAL, "unknown profile tag %s", tag);
+    h->prof_mode = 1; h->prof_tag = t;
+    return KEEP_OK;
+}
+int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches) {
+    if (!h || !tag) return KEEP_EINVAL;
+    const int t = tag_by_name(tag);
+    if (t < 0) return h->fail(KEEP_EINVAL, "unknown profile tag %s", tag);
+    hipSetDevice(h->device);
+    h->prof_collect();
+    if (total_ms) *total_ms = h->prof_ms[t];
+    if (launches) *launches = h->prof_n[t];
+    return KEEP_OK;
+}
+int keep_profile_reset(keep_handle* h) {
+    if (!h) return KEEP_EINVAL;
+    hipSetDevice(h->device);
+    h->prof_collect();
+    for (int i = 0; i < T_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    return KEEP_OK;
+}
+
+// ---------------------------------------------------------------- single-operator entry points
+int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls, const float* resid,
+                   int64_t M, int64_t N, int64_t K, int epi, int split, float* out, void* stream) {
+    if (!h || !a || !w || !bias || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
+    if (M < 1 || N % 128 || K % 64 || N < 128 || K < 64) return h->fail(KEEP_EUNSUPPORTED, "linear needs N%%128==0, K%%64==0");
+    if (epi != EPI_F16 && epi != EPI_GELU_F16 && epi != EPI_RESID_LS && epi != EPI_RESID_F32) return h->fail(KEEP_EINVAL, "epilogue %d", epi);
+    if ((epi == EPI_RESID_LS && (!ls || !resid)) || (epi == EPI_RESID_F32 && !resid)) return h->fail(KEEP_EINVAL, "missing ls/resid");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Tmp t;
+    f16* a_hi = t.get<f16>(M * K); f16* a_lo = t.get<f16>(M * K);
+    f16* w_hi = t.get<f16>(N * K); f16* w_lo = t.get<f16>(N * K);
+    f16* o_hi = t.get<f16>(M * N); f16* o_lo = t.get<f16>(M * N);
+    if (!a_hi || !a_lo || !w_hi || !w_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
+    launch_split_f16(a, a_hi, a_lo, M * K, s);
+    launch_split_f16(w, w_hi, w_lo, N * K, s);
+    GemmParams p{};
+    p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.nseg = split ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
+    if (epi == EPI_F16 || epi == EPI_GELU_F16) {
+        p.out_hi = o_hi; p.out_lo = split ? o_lo : nullptr;
+        launch_gemm_f16(p, epi, s);
+        planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * N, s);
+    } else if (epi == EPI_RESID_LS) {
+        HIPCHK(h, hipMemcpyAsync(out, resid, M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        p.resid = out;
+        launch_gemm_f16(p, epi, s);
+    } else {
+        p.resid = const_cast<float*>(resid); p.out_f32 = out;
+        launch_gemm_f16(p, epi, s);
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    return check_launch(h, "op_linear");
+}
+
+int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int64_t B, int64_t T, int heads, int split,
+                      float* out, void* stream) {
+    if (!h || !qkv || !out || B < 1 || T < 1 || heads < 1) return h ? h->fail(KEEP_EINVAL, "bad attention arguments") : KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = B * T, D = (int64_t)heads * 64;
+    Tmp t;
+    f16* q_hi = t.get<f16>(M * 3 * D); f16* q_lo = t.get<f16>(M * 3 * D);
+    f16* o_hi = t.get<f16>(M * D); f16* o_lo = t.get<f16>(M * D);
+    if (!q_hi || !q_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
+    launch_split_f16(qkv, q_hi, q_lo, M * 3 * D, s);
+    AttnParams a{};
+    a.qkv_hi = q_hi; a.qkv_lo = q_lo; a.out_hi = o_hi; a.out_lo = split ? o_lo : nullptr; a.mask = mask;
+    a.batch = (int)B; a.ntok = (int)T; a.heads = heads; a.split = split; a.scale = 0.125f;
+    if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
+    planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * D, s);
+    HIPCHK(h, hipStreamSynchronize(s));
+    return check_launch(h, "op_attention");
+}
+
+int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const float* gamma, const float* beta, int64_t rows,
+                      int64_t D, float eps, float* out, void* stream) {
+    if (!h || !x || !gamma || !beta || !out || rows < 1) return h ? h->fail(KEEP_EINVAL, "bad layernorm arguments") : KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    LnParams p{};
+    p.x = x; p.x_stride = D; p.add = add; p.gamma = gamma; p.beta = beta; p.rows = (int)rows; p.D = (int)D; p.eps = eps;
+    p.out_f32 = out; p.out_f32_stride = D;
+    if (launch_layernorm(p, (hipStream_t)stream)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %lld", (long long)D);
+    return check_launch(h, "op_layernorm");
+}
+
+int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* bias, int64_t M, int64_t N, int64_t K, float scale,
+                  int act, float* out, void* stream) {
+    if (!h || !a || !b || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    SgemmParams g{};
+    g.a = a; g.lda = K; g.b = b; g.ldb = K; g.out = out; g.ldo = N; g.bias = bias; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.scale = scale; g.act = act;
+    if (launch_sgemm_f32(g, (hipStream_t)stream)) return h->fail(KEEP_EUNSUPPORTED, "sgemm needs K%%16==0");
+    return check_launch(h, "op_sgemm");
+}
+
+int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream) {
+    if (!h || !x || rows < 1 || D < 1) return h ? h->fail(KEEP_EINVAL, "bad l2norm arguments") : KEEP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_l2norm_rows(x, (int)rows, (int)D, 1e-12f, (hipStream_t)stream);
+    return check_launch(h, "op_l2norm");
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// fp16-operand / fp32-accumulate MFMA GEMM with fused epilogues (gfx950).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]          A: activations [M][K], W: torch Linear weight [N][K]
+//
+// This is the arithmetic behind every nn.Linear / the patch-embed conv of the two
+// towers (timm Block: qkv, proj, fc1, fc2 -- SURVEY.md §A.1; HF BertLayer: q/k/v,
+// attention.output.dense, intermediate.dense, output.dense -- §A.2).
+//
+// Tiling (v1, "128x128x64 / 4 waves"):
+//   * workgroup = 256 threads = 4 wavefronts (2 along M x 2 along N), tile 128x128, BK = 64
+//   * each wave owns 64x64 = 2x2 MFMA 32x32x16 tiles (64 fp32 accumulators / lane)
+//   * MFMA operand swap: the "A" operand carries W rows (n) and the "B" operand activation rows
+//     (m), so a lane's C fragment is 4 consecutive n of ONE m -> 8/16-byte epilogue stores
+//   * global -> VGPR -> LDS staging, LDS double-buffered, one barrier per K step
+//   * LDS rows are 128 B; the 16-B slot index is XORed with (row>>1)&7 which makes both the
+//     ds_write_b128 (8-lane groups) and the ds_read_b128 (16-lane groups) conflict free
+//   * nseg == 3 runs the hi/lo split product  A_hi*W_hi + A_lo*W_hi + A_hi*W_lo  through the same
+//     accumulators (strict precision mode)
+#include "common.h"
+
+namespace keepk {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int THREADS = 256;
+constexpr int TILE_ELEMS = BM * BK;            // 8192 f16 = 16 KiB per operand per buffer
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    // element offset of 16-byte chunk `chunk` (0..7) of tile row `row` (0..127)
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(THREADS, 2)
+void gemm_f16_nt_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) f16 lds[2 * 2 * TILE_ELEMS];   // [buf][A|W][128*64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+
+    // ---- staging coordinates: 4 chunks of 16 B per thread per operand
+    int st_row[4], st_chunk[4];
+    const f16* ga[4]; const f16* gw[4];      // row base pointers (hi plane), advanced by k
+    int64_t a_row_off[4], w_row_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + THREADS * i;
+        st_row[i] = q >> 3;
+        st_chunk[i] = q & 7;
+        int am = m0 + st_row[i]; if (am > p.M - 1) am = p.M - 1;     // clamp: rows >= M are never stored
+        a_row_off[i] = (int64_t)am * p.K + st_chunk[i] * 8;
+        w_row_off[i] = (int64_t)(n0 + st_row[i]) * p.K + st_chunk[i] * 8;
+    }
+
+    const int ktiles = p.K / BK;
+    const int steps = ktiles * p.nseg;
+
+    f16x8 ra[4], rw[4];
+    auto load_global = [&](int s) {
+        const int seg = s / ktiles;
+        const int kk = (s - seg * ktiles) * BK;
+        const f16* ab = (seg == 1) ? p.a_lo : p.a_hi;
+        const f16* wb = (seg == 2) ? p.w_lo : p.w_hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const f16x8*>(ab + a_row_off[i] + kk);
+            rw[i] = *reinterpret_cast<const f16x8*>(wb + w_row_off[i] + kk);
+        }
+    };
+    auto store_lds = [&](int buf) {
+        f16* sa = lds + buf * 2 * TILE_ELEMS;
+        f16* sw = sa + TILE_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = lds_off(st_row[i], st_chunk[i]);
+            *reinterpret_cast<f16x8*>(sa + o) = ra[i];
+            *reinterpret_cast<f16x8*>(sw + o) = rw[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    const int frow = lane & 31;
+    const int fhi = lane >> 5;
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) load_global(s + 1);
+        const f16* sa = lds + buf * 2 * TILE_ELEMS;
+        const f16* sw = sa + TILE_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 fw[2], fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fw[i] = *reinterpret_cast<const f16x8*>(sw + lds_off(wn * 64 + i * 32 + frow, ks * 2 + fhi));
+                fa[i] = *reinterpret_cast<const f16x8*>(sa + lds_off(wm * 64 + i * 32 + frow, ks * 2 + fhi));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < steps) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[i][j][r]: n = n0 + wn*64 + i*32 + (r&3) + 8*(r>>2) + 4*fhi ; m = m0 + wm*64 + j*32 + frow
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 64 + j * 32 + frow;
+        if (m >= p.M) continue;
+        int64_t orow = m;
+        int prow = 0;
+        if (EPI == EPI_PATCH) {
+            const int b = m / p.patches_per_img;
+            prow = m - b * p.patches_per_img + 1;
+            orow = (int64_t)b * (p.patches_per_img + 1) + prow;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * fhi;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bias[e];
+                const int64_t o = orow * p.N + n;
+                if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
+                    if (EPI == EPI_GELU_F16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    f16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { f16 hh, ll; split_f16(v[e], hh, ll); h[e] = hh; l[e] = ll; }
+                    *reinterpret_cast<f16x4*>(p.out_hi + o) = h;
+                    if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + o) = l;
+                } else if (EPI == EPI_RESID_LS) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls + n);
+                    f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] += g[e] * v[e];
+                    *reinterpret_cast<f32x4*>(p.resid + o) = r;
+                } else if (EPI == EPI_PATCH) {
+                    const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += pe[e];
+                    *reinterpret_cast<f32x4*>(p.resid + o) = v;
+                } else {   // EPI_RESID_F32
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace keepk
+using namespace keepk;
+
+void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s) {
+    dim3 grid(p.N / BN, (p.M + BM - 1) / BM), block(THREADS);
+    switch (epi) {
+        case EPI_F16:       hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_F16>, grid, block, 0, s, p); break;
+        case EPI_GELU_F16:  hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_GELU_F16>, grid, block, 0, s, p); break;
+        case EPI_RESID_LS:  hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_RESID_LS>, grid, block, 0, s, p); break;
+        case EPI_PATCH:     hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_PATCH>, grid, block, 0, s, p); break;
+        default:            hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_RESID_F32>, grid, block, 0, s, p); break;
+    }
+}

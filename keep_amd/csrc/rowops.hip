@@ -1,0 +1,338 @@
+// Row-wise / elementwise kernels around the GEMMs (all HBM-bound; 16-byte accesses per lane,
+// one 64-lane wavefront per row where a row reduction is involved).
+//
+//   layernorm        timm nn.LayerNorm(eps=1e-6) / HF BertLayerNorm(eps=1e-12)
+//   im2col           the reshape that turns timm PatchEmbed's conv16/s16 into a GEMM
+//   bert_embed_ln    HF BertEmbeddings: word + position + token_type -> LayerNorm
+//   l2norm_rows      F.normalize(x, dim=-1)                      keep_inference.py:56,61
+//   row_argmax / row_softmax / top2_score
+//                    argmax of raw cosine, softmax(10*logits) (subtyping_utils.py:72) and
+//                    rank_cls_score (WSI_evaluation/utils.py:107-117)
+#include "common.h"
+
+namespace keepk {
+
+// ------------------------------------------------------------------ LayerNorm
+template <int NV>   // NV float4 per lane: D = NV * 256
+__global__ __launch_bounds__(256)
+void layernorm_kernel(LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const float* x = p.x + (int64_t)row * p.x_stride;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(x + (i * 64 + lane) * 4);
+        if (p.add) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.add + (int64_t)row * p.x_stride + (i * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += a[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += v[i][e];
+    }
+    const float mean = wave_sum(sum) * (1.0f / (NV * 256));
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] -= mean; sq += v[i][e] * v[i][e]; }
+    const float var = wave_sum(sq) * (1.0f / (NV * 256));
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + col);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + col);
+        f32x4 y;
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = v[i][e] * rstd * g[e] + bt[e];
+            f16 hh, ll; split_f16(y[e], hh, ll); h[e] = hh; l[e] = ll;
+        }
+        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (int64_t)row * p.out_f32_stride + col) = y;
+        if (p.out_hi) *reinterpret_cast<f16x4*>(p.out_hi + (int64_t)row * (NV * 256) + col) = h;
+        if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + (int64_t)row * (NV * 256) + col) = l;
+    }
+}
+
+// ------------------------------------------------------------------ im2col for the patch embed
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+template <int DT>
+__global__ __launch_bounds__(256)
+void im2col_kernel(const void* __restrict__ pixels, int B, f16* __restrict__ out_hi, f16* __restrict__ out_lo) {
+    // one work item = 8 consecutive pixels of one image row: (b, c, y, xc) with xc in [0,28)
+    const int64_t total = (int64_t)B * 3 * 224 * 28;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int xc = (int)(it % 28);
+        int64_t r = it / 28;
+        const int y = (int)(r % 224); r /= 224;
+        const int c = (int)(r % 3);
+        const int b = (int)(r / 3);
+        const int64_t src = (((int64_t)b * 3 + c) * 224 + y) * 224 + xc * 8;
+        float v[8];
+        if (DT == PIX_F32) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)pixels + src);
+            const f32x4 d = *reinterpret_cast<const f32x4*>((const float*)pixels + src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = d[e]; }
+        } else if (DT == PIX_F16) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>((const f16*)pixels + src);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+        } else {
+            const uint4 a = *reinterpret_cast<const uint4*>((const unsigned short*)pixels + src);
+            const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = bf16_to_f32((unsigned short)(w[e] & 0xffffu));
+                v[2 * e + 1] = bf16_to_f32((unsigned short)(w[e] >> 16));
+            }
+        }
+        const int py = y >> 4, ph = y & 15, px = xc >> 1, half = xc & 1;
+        const int64_t dst = ((int64_t)b * 196 + py * 14 + px) * 768 + c * 256 + ph * 16 + half * 8;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f16 hh, ll; split_f16(v[e], hh, ll); h[e] = hh; l[e] = ll; }
+        *reinterpret_cast<f16x8*>(out_hi + dst) = h;
+        if (out_lo) *reinterpret_cast<f16x8*>(out_lo + dst) = l;
+    }
+}
+
+__global__ void cls_init_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ resid,
+                                int B, int D, int ntok) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * D) return;
+    const int b = (int)(i / D), d = (int)(i % D);
+    resid[(int64_t)b * ntok * D + d] = cls[d] + pos[d];
+}
+
+// ------------------------------------------------------------------ elementwise split (weight prep)
+__global__ void split_f16_kernel(const float* __restrict__ src, f16* __restrict__ hi, f16* __restrict__ lo, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        f16 h, l; split_f16(src[i], h, l);
+        hi[i] = h;
+        if (lo) lo[i] = l;
+    }
+}
+
+// ------------------------------------------------------------------ row L2 normalise (in place)
+__global__ __launch_bounds__(256)
+void l2norm_rows_kernel(float* __restrict__ x, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* r = x + (int64_t)row * D;
+    float sq = 0.f;
+    for (int i = lane; i < D; i += 64) sq += r[i] * r[i];
+    const float nrm = sqrtf(wave_sum(sq));
+    const float inv = 1.0f / fmaxf(nrm, eps);
+    for (int i = lane; i < D; i += 64) r[i] *= inv;
+}
+
+// ------------------------------------------------------------------ row argmax (first max wins)
+__global__ __launch_bounds__(256)
+void row_argmax_kernel(const float* __restrict__ x, int rows, int cols, int32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* r = x + (int64_t)row * cols;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < cols; i += 64) {
+        const float v = r[i];
+        if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) out[row] = bi;
+}
+
+// ------------------------------------------------------------------ row softmax(scale * x)
+template <typename OutT>
+__global__ __launch_bounds__(256)
+void row_softmax_kernel(const float* __restrict__ x, int rows, int cols, float scale, OutT* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* r = x + (int64_t)row * cols;
+    float mx = -INFINITY;
+    for (int i = lane; i < cols; i += 64) mx = fmaxf(mx, r[i] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < cols; i += 64) sum += expf(r[i] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < cols; i += 64) out[(int64_t)row * cols + i] = (OutT)(expf(r[i] * scale - mx) * inv);
+}
+
+// ------------------------------------------------------------------ rank_cls_score: mean_t[(v1-v2) - |v1+v2-1|]
+__global__ __launch_bounds__(256)
+void top2_partial_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ partial) {
+    // one thread per row (cols is the class count, 2..8); block partial sums -> partial[blockIdx.x]
+    __shared__ float red[4];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    float sc = 0.f;
+    if (row < rows) {
+        const float* r = x + (int64_t)row * cols;
+        float v1 = -INFINITY, v2 = -INFINITY;
+        for (int i = 0; i < cols; ++i) {
+            const float v = r[i];
+            if (v > v1) { v2 = v1; v1 = v; } else if (v > v2) { v2 = v; }
+        }
+        sc = (v1 - v2) - fabsf(v1 + v2 - 1.0f);
+    }
+    sc = wave_sum(sc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256)
+void top2_final_kernel(const float* __restrict__ partial, int n, int rows, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)rows;
+}
+
+// ------------------------------------------------------------------ BERT embeddings + LayerNorm
+template <int NV>
+__global__ __launch_bounds__(256)
+void bert_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ type_ids,
+                          const float* __restrict__ wemb, const float* __restrict__ pemb, const float* __restrict__ temb,
+                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                          int rows, int T, int vocab, int type_vocab,
+                          float* __restrict__ resid, f16* __restrict__ out_hi, f16* __restrict__ out_lo, int* err_flag) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int64_t id = ids[row];
+    int64_t ty = type_ids ? type_ids[row] : 0;
+    if (id < 0 || id >= vocab || ty < 0 || ty >= type_vocab) {
+        if (lane == 0) atomicOr(err_flag, 1);
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        ty = ty < 0 ? 0 : (ty >= type_vocab ? type_vocab - 1 : ty);
+    }
+    const int t = row % T;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wemb + id * D + col);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pemb + (int64_t)t * D + col);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(temb + ty * D + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = (a[e] + c[e]) + b[e]; sum += v[i][e]; }   // HF BertEmbeddings order: (word + token_type) + position
+    }
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] -= mean; sq += v[i][e] * v[i][e]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + col);
+        f32x4 y; f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = v[i][e] * rstd * g[e] + bt[e];
+            f16 hh, ll; split_f16(y[e], hh, ll); h[e] = hh; l[e] = ll;
+        }
+        *reinterpret_cast<f32x4*>(resid + (int64_t)row * D + col) = y;
+        *reinterpret_cast<f16x4*>(out_hi + (int64_t)row * D + col) = h;
+        if (out_lo) *reinterpret_cast<f16x4*>(out_lo + (int64_t)row * D + col) = l;
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst, int rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * D) return;
+    const int r = (int)(i / D), d = (int)(i % D);
+    dst[i] = src[(int64_t)r * src_stride + d];
+}
+
+}  // namespace keepk
+using namespace keepk;
+
+int launch_layernorm(const LnParams& p, hipStream_t s) {
+    dim3 grid((p.rows + 3) / 4), block(256);
+    if (p.D == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, p);
+    else if (p.D == 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, p);
+    else if (p.D == 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, p);
+    else if (p.D == 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, p);
+    else return -1;
+    return 0;
+}
+
+void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_lo,
+                   const float* cls, const float* pos, float* resid, int D, hipStream_t s) {
+    const int64_t total = (int64_t)B * 3 * 224 * 28;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (dtype == PIX_F32) hipLaunchKernelGGL(im2col_kernel<PIX_F32>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
+    else if (dtype == PIX_F16) hipLaunchKernelGGL(im2col_kernel<PIX_F16>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
+    else hipLaunchKernelGGL(im2col_kernel<PIX_BF16>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
+    const int64_t n = (int64_t)B * D;
+    hipLaunchKernelGGL(cls_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cls, pos, resid, B, D, 197);
+}
+
+void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(split_f16_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, n);
+}
+
+void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, D, eps);
+}
+void launch_row_argmax(const float* x, int rows, int cols, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(row_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, cols, out);
+}
+void launch_row_softmax(const float* x, int rows, int cols, float scale, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(row_softmax_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, cols, scale, out);
+}
+void launch_row_softmax_f16(const float* x, int rows, int cols, float scale, f16* out, hipStream_t s) {
+    hipLaunchKernelGGL(row_softmax_kernel<f16>, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, cols, scale, out);
+}
+void launch_top2_score(const float* x, int rows, int cols, float* partial, float* out, hipStream_t s) {
+    const int nb = (rows + 255) / 256;
+    hipLaunchKernelGGL(top2_partial_kernel, dim3(nb), dim3(256), 0, s, x, rows, cols, partial);
+    hipLaunchKernelGGL(top2_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, rows, out);
+}
+void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const float* wemb, const float* pemb,
+                          const float* temb, const float* gamma, const float* beta, float eps,
+                          int P, int T, int D, int vocab, int type_vocab,
+                          float* resid, f16* out_hi, f16* out_lo, int* err_flag, hipStream_t s) {
+    const int rows = P * T;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (D == 768)
+        hipLaunchKernelGGL(bert_embed_ln_kernel<3>, grid, block, 0, s, ids, type_ids, wemb, pemb, temb, gamma, beta, eps,
+                           rows, T, vocab, type_vocab, resid, out_hi, out_lo, err_flag);
+    else if (D == 1024)
+        hipLaunchKernelGGL(bert_embed_ln_kernel<4>, grid, block, 0, s, ids, type_ids, wemb, pemb, temb, gamma, beta, eps,
+                           rows, T, vocab, type_vocab, resid, out_hi, out_lo, err_flag);
+    else
+        hipLaunchKernelGGL(bert_embed_ln_kernel<1>, grid, block, 0, s, ids, type_ids, wemb, pemb, temb, gamma, beta, eps,
+                           rows, T, vocab, type_vocab, resid, out_hi, out_lo, err_flag);
+}
+void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s) {
+    const int64_t n = (int64_t)rows * D;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_stride, dst, rows, D);
+}

@@ -1,0 +1,342 @@
+"""Host-side mirror of the reference's model API on top of libkeep_hip.
+
+``KEEPModel`` keeps the surface of ``KEEPModel`` in ``quick_start/keep_inference.py:25-73`` (the
+class HF ``AutoModel.from_pretrained('Astaxanthin/KEEP', trust_remote_code=True)`` returns in
+``WSI_evaluation/zeroshot_*_WSI.py``): ``encode_image``, ``encode_text``, ``forward``, ``eval``,
+``to``, ``load_state_dict``, ``logit_scale`` -- same argument meaning, same output shapes/dtypes,
+L2-normalised fp32 features on the caller's device.  Underneath there is no torch module: tensors
+are handed to the C ABI as raw device pointers; torch supplies storage, streams and file loading.
+
+There is no CPU execution path.  Inputs that live on the CPU are copied to the engine's GPU and the
+result is copied back; without a GPU (or without libkeep_hip.so) every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from typing import Dict, Mapping, Optional, Union
+
+import torch
+
+from . import _lib
+from .config import KEEPShape
+
+_PIX = {torch.float32: _lib.PIX_F32, torch.float16: _lib.PIX_F16, torch.bfloat16: _lib.PIX_BF16}
+_PRECISIONS = {"fp16": _lib.PREC_FP16, "strict": _lib.PREC_STRICT}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(device: torch.device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class KEEPModel:
+    """Drop-in for the reference ``KEEPModel`` (inference only)."""
+
+    def __init__(self, config: Optional[Union[KEEPShape, Mapping, str]] = None, precision: str = "fp16"):
+        if config is None:
+            config = KEEPShape()
+        elif not isinstance(config, KEEPShape):
+            config = KEEPShape.from_config_json(config)
+        self.config = config
+        # nn.Parameter(torch.ones([]) * log(1/0.04)) -- keep_inference.py:52 (never applied at inference)
+        self.logit_scale = torch.tensor(config.logit_scale_init, dtype=torch.float32)
+        self.training = False
+        self._handle = C.c_void_p(0)
+        self._device: Optional[torch.device] = None
+        self._host_sd: Optional[Dict[str, torch.Tensor]] = None
+        self._loaded = False
+        self._options = {"precision": _PRECISIONS[precision], "strict_blocks": 0}
+        self.check_token_ids = True
+
+    # ------------------------------------------------------------------ lifetime
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _destroy(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            _lib.load().keep_destroy(self._handle)
+            self._handle = C.c_void_p(0)
+            self._loaded = False
+
+    def _create(self, device: torch.device):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.KeepHipError("no GPU visible: keep_amd has no CPU execution path")
+        if device.type != "cuda":
+            raise ValueError(f"keep_amd runs on a ROCm GPU ('cuda:N'), not on {device}")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = C.c_void_p(0)
+        rc = lib.keep_create(idx, C.byref(h))
+        if rc != _lib.KEEP_OK:
+            raise _lib.KeepHipError(f"keep_create(device={idx}) failed with code {rc}")
+        self._handle = h
+        self._device = torch.device("cuda", idx)
+        for k, v in self._options.items():
+            _lib.check(h, lib.keep_set_option(h, k.encode(), float(v)), k)
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("keep_amd is an inference engine; training is out of scope")
+        return self.eval()
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._device if self._device is not None else torch.device("cpu")
+
+    def to(self, device=None, *args, **kwargs):
+        if device is None:
+            return self
+        device = torch.device(device)
+        if device.type == "cpu":
+            if self._loaded:
+                raise _lib.KeepHipError("keep_amd has no CPU execution path; the model stays on its GPU")
+            return self
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        if self._loaded and self._device == device:
+            return self
+        if self._loaded and self._host_sd is None:
+            raise _lib.KeepHipError("weights were already uploaded and the host copy released; "
+                                    "reload the state_dict to move to another GPU")
+        self._destroy()
+        self._create(device)
+        if self._host_sd is not None:
+            self._upload(self._host_sd)
+            self._host_sd = None
+        return self
+
+    cuda = lambda self, device=None: self.to(torch.device("cuda", device) if isinstance(device, int) else (device or "cuda"))
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict: Mapping[str, torch.Tensor], strict: bool = True):
+        """``model.load_state_dict(state_dict, strict=True)`` -- keep_inference.py:83.
+
+        Key layout: SURVEY.md §A.3.  On a model that is already on a GPU the tensors are repacked
+        immediately; otherwise they are held (by reference) until ``.to('cuda')``.
+        """
+        sd = {k: v for k, v in state_dict.items()}
+        if "logit_scale" in sd:
+            self.logit_scale = sd["logit_scale"].detach().to("cpu", torch.float32).reshape(())
+        self._strict = strict
+        if self._handle.value:
+            self._upload(sd)
+        else:
+            self._host_sd = sd
+        return self
+
+    def _upload(self, sd: Mapping[str, torch.Tensor]):
+        lib, h = _lib.load(), self._handle
+        errors = []
+        for key, t in sd.items():
+            if not isinstance(t, torch.Tensor):
+                continue
+            t = t.detach()
+            on_dev = t.device.type == "cuda" and t.device == self._device
+            src = t.to(torch.float32).contiguous() if on_dev else t.to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(src.dim(), 1))(*src.shape)
+            rc = lib.keep_load_tensor(h, key.encode(), _ptr(src), src.dim(), shape, 1 if on_dev else 0)
+            if rc == _lib.KEEP_EKEY:
+                if getattr(self, "_strict", True):
+                    errors.append(lib.keep_last_error(h).decode())
+            else:
+                _lib.check(h, rc, key)
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\t" + "\n\t".join(errors))
+        rc = lib.keep_finalize_weights(h)
+        if rc == _lib.KEEP_EKEY:
+            raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\t" + lib.keep_last_error(h).decode())
+        _lib.check(h, rc, "finalize_weights")
+        self._loaded = True
+
+    @classmethod
+    def from_pretrained(cls, path: str, precision: str = "fp16", **_ignored) -> "KEEPModel":
+        """Load a release directory (``config.json`` + ``pytorch_model.bin`` or ``model.safetensors``),
+        the local-files equivalent of ``AutoModel.from_pretrained`` at zeroshot_subtyping_WSI.py:44."""
+        cfg_path = os.path.join(path, "config.json")
+        config = KEEPShape.from_config_json(cfg_path) if os.path.exists(cfg_path) else KEEPShape()
+        model = cls(config, precision=precision)
+        st = os.path.join(path, "model.safetensors")
+        pt = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        elif os.path.exists(pt):
+            sd = torch.load(pt, map_location="cpu")
+        else:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+        model.load_state_dict(sd, strict=True)
+        return model
+
+    # ------------------------------------------------------------------ options
+    def set_precision(self, precision: str = "fp16", strict_blocks: int = 0):
+        """'fp16': fp16 MFMA operands / fp32 accumulate (fast).  'strict': hi/lo split operands,
+        three MFMA passes (fp32-class accuracy, ~3x the GEMM time).  ``strict_blocks=n`` runs only the
+        first n transformer blocks of each tower in split mode."""
+        self._options["precision"] = _PRECISIONS[precision]
+        self._options["strict_blocks"] = int(strict_blocks)
+        if self._handle.value:
+            lib = _lib.load()
+            for k, v in self._options.items():
+                _lib.check(self._handle, lib.keep_set_option(self._handle, k.encode(), float(v)), k)
+        return self
+
+    def set_option(self, name: str, value: float):
+        self._options[name] = value
+        if self._handle.value:
+            _lib.check(self._handle, _lib.load().keep_set_option(self._handle, name.encode(), float(value)), name)
+        return self
+
+    def reserve(self, tiles: int = 0, prompts: int = 0, seq: int = 256):
+        self._ready()
+        _lib.check(self._handle, _lib.load().keep_reserve(self._handle, tiles, prompts, seq), "reserve")
+        return self
+
+    def _ready(self):
+        if not self._loaded:
+            if self._host_sd is not None:
+                self.to("cuda")            # reference scripts call .to(device) themselves; be lenient
+            else:
+                raise _lib.KeepHipError("no weights loaded: call load_state_dict / from_pretrained first")
+
+    # ------------------------------------------------------------------ the hot path
+    @torch.no_grad()
+    def encode_image(self, image_inputs: torch.Tensor) -> torch.Tensor:
+        """keep_inference.py:54-58: normalize(visual_head(visual(x)), dim=-1) -> [B, 768] fp32."""
+        self._ready()
+        x = image_inputs
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected [B,3,224,224], got {tuple(x.shape)}")
+        if x.shape[2] != 224 or x.shape[3] != 224:
+            raise ValueError("only 224x224 tiles are supported (the reference would resample pos_embed via "
+                             "timm dynamic_img_size; every reference caller feeds 224x224)")
+        if x.dtype not in _PIX:
+            x = x.to(torch.float32)
+        src_dev = x.device
+        if x.shape[0] == 0:
+            return torch.empty((0, self.config.projection_dim), dtype=torch.float32, device=src_dev)
+        xd = x.to(self._device, non_blocking=True).contiguous()
+        out = torch.empty((xd.shape[0], self.config.projection_dim), dtype=torch.float32, device=self._device)
+        lib = _lib.load()
+        _lib.check(self._handle, lib.keep_encode_image(self._handle, _ptr(xd), _PIX[xd.dtype], xd.shape[0], _ptr(out),
+                                                       _stream(self._device)), "encode_image")
+        return out if src_dev == self._device else out.to(src_dev)
+
+    @torch.no_grad()
+    def encode_text(self, text_inputs: Mapping[str, torch.Tensor]) -> torch.Tensor:
+        """keep_inference.py:60-62: normalize(text(**inputs).pooler_output, dim=-1) -> [P, 768] fp32."""
+        self._ready()
+        ids = text_inputs["input_ids"]
+        if ids.dim() != 2:
+            raise ValueError(f"input_ids must be [P,T], got {tuple(ids.shape)}")
+        src_dev = ids.device
+        if ids.shape[0] == 0:
+            return torch.empty((0, self.config.text.hidden_size), dtype=torch.float32, device=src_dev)
+
+        def prep(name):
+            t = text_inputs.get(name) if hasattr(text_inputs, "get") else (text_inputs[name] if name in text_inputs else None)
+            if t is None:
+                return None
+            if tuple(t.shape) != tuple(ids.shape):
+                raise ValueError(f"{name} shape {tuple(t.shape)} != input_ids shape {tuple(ids.shape)}")
+            return t.to(self._device, torch.int64, non_blocking=True).contiguous()
+
+        ids_d = ids.to(self._device, torch.int64, non_blocking=True).contiguous()
+        typ_d, msk_d = prep("token_type_ids"), prep("attention_mask")
+        P, T = ids_d.shape
+        out = torch.empty((P, self.config.text.hidden_size), dtype=torch.float32, device=self._device)
+        lib = _lib.load()
+        st = _stream(self._device)
+        _lib.check(self._handle, lib.keep_encode_text(self._handle, _ptr(ids_d), _ptr(typ_d), _ptr(msk_d), P, T,
+                                                      _ptr(out), st), "encode_text")
+        if self.check_token_ids and lib.keep_token_error(self._handle, st) == 1:
+            raise IndexError("index out of range in self (input_ids / token_type_ids outside the embedding tables)")
+        return out if src_dev == self._device else out.to(src_dev)
+
+    def forward(self, image_inputs, text_inputs):
+        """keep_inference.py:65-73."""
+        return {"vision_features": self.encode_image(image_inputs),
+                "text_features": self.encode_text(text_inputs)}
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ similarity
+    @torch.no_grad()
+    def similarity(self, image_features: torch.Tensor, text_features: torch.Tensor, scale: float = 1.0,
+                   mode: str = "raw"):
+        """Tile x prompt similarity on the GPU.
+
+        mode 'raw'     -> scale * I @ T^T                       [N,P] fp32   (keep_inference.py:104)
+             'argmax'  -> (sim [N,P], labels [N] int32)
+             'softmax' -> softmax(scale * I @ T^T, dim=1)       [N,P] fp32   (subtyping_utils.py:72, scale=10)
+             'softmax_f16' -> same in fp16
+             'top2score'   -> python float, rank_cls_score of I @ T^T (WSI_evaluation/utils.py:107-117)
+        """
+        self._ready_device()
+        img = image_features.to(self._device, torch.float32).contiguous()
+        txt = text_features.to(self._device, torch.float32).contiguous()
+        if img.dim() != 2 or txt.dim() != 2 or img.shape[1] != txt.shape[1]:
+            raise ValueError(f"feature shapes {tuple(img.shape)} x {tuple(txt.shape)}")
+        N, D = img.shape
+        P = txt.shape[0]
+        lib, st = _lib.load(), _stream(self._device)
+        code = {"raw": _lib.SIM_RAW, "argmax": _lib.SIM_ARGMAX, "softmax": _lib.SIM_SOFTMAX,
+                "softmax_f16": _lib.SIM_SOFTMAX_F16, "top2score": _lib.SIM_TOP2SCORE}[mode]
+        amax = None
+        if mode == "top2score":
+            out = torch.empty((1,), dtype=torch.float32, device=self._device)
+        elif mode == "softmax_f16":
+            out = torch.empty((N, P), dtype=torch.float16, device=self._device)
+        else:
+            out = torch.empty((N, P), dtype=torch.float32, device=self._device)
+        if mode == "argmax":
+            amax = torch.empty((N,), dtype=torch.int32, device=self._device)
+        _lib.check(self._handle, lib.keep_similarity(self._handle, _ptr(img), _ptr(txt), N, P, D, float(scale), code,
+                                                     _ptr(out), _ptr(amax), st), "similarity")
+        if mode == "argmax":
+            return out, amax
+        if mode == "top2score":
+            return float(out.item())
+        return out
+
+    def _ready_device(self):
+        if not self._handle.value:
+            self._create(torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0))
+
+    # ------------------------------------------------------------------ profiling passthrough
+    def profile_enable(self, tag: Optional[str] = None):
+        self._ready_device()
+        arg = None if tag is None else tag.encode()
+        _lib.check(self._handle, _lib.load().keep_profile_enable(self._handle, arg), "profile_enable")
+
+    def profile_disable(self):
+        self.profile_enable("")
+
+    def profile_reset(self):
+        _lib.check(self._handle, _lib.load().keep_profile_reset(self._handle), "profile_reset")
+
+    def profile_read(self, tag: str):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _lib.check(self._handle, _lib.load().keep_profile_read(self._handle, tag.encode(), C.byref(ms), C.byref(n)), tag)
+        return ms.value, n.value
+
+
+PROFILE_TAGS = ("vit.im2col", "vit.patch", "vit.ln", "vit.qkv", "vit.attn", "vit.proj", "vit.fc1", "vit.fc2",
+                "vit.head", "text.embed", "text.ln", "text.qkv", "text.attn", "text.out", "text.ffn1", "text.ffn2",
+                "text.pool", "sim")

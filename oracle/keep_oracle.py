@@ -157,8 +157,8 @@ def bert_pooled(sd, input_ids: Tensor, token_type_ids: Optional[Tensor], attenti
     if attention_mask is None:
         attention_mask = torch.ones_like(input_ids)
     e = (sd[prefix + "embeddings.word_embeddings.weight"][input_ids]
-         + sd[prefix + "embeddings.position_embeddings.weight"][:T][None]
-         + sd[prefix + "embeddings.token_type_embeddings.weight"][token_type_ids])
+         + sd[prefix + "embeddings.token_type_embeddings.weight"][token_type_ids]
+         + sd[prefix + "embeddings.position_embeddings.weight"][:T][None])
     h = layer_norm(e, sd[prefix + "embeddings.LayerNorm.weight"], sd[prefix + "embeddings.LayerNorm.bias"], eps)
     H = h.shape[-1]
     hd = H // heads

@@ -1,0 +1,55 @@
+"""Repository contract: the product never touches the oracle; required files exist."""
+import ast
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def py_files(d):
+    for base, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(".py"):
+                yield os.path.join(base, f)
+
+
+def imported_modules(path):
+    tree = ast.parse(open(path).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            for a in node.names:
+                yield a.name
+        elif isinstance(node, ast.ImportFrom) and node.module:
+            yield node.module
+
+
+def test_product_package_never_imports_oracle_or_reference():
+    for f in py_files(os.path.join(ROOT, "keep_amd")):
+        src = open(f).read()
+        assert "/root/reference" not in src, f
+        for m in imported_modules(f):
+            assert not m.startswith("oracle"), f"{f} imports {m}"
+            assert not m.startswith("transformers") and not m.startswith("timm"), f"{f} imports {m}"
+
+
+def test_csrc_has_no_compat_layers():
+    for base, _, files in os.walk(os.path.join(ROOT, "keep_amd", "csrc")):
+        for f in files:
+            src = open(os.path.join(base, f)).read()
+            for bad in ("__HIP_PLATFORM_AMD__", "cuda_runtime", "hipify", "triton", "__CUDA_ARCH__"):
+                assert bad not in src, (f, bad)
+
+
+def test_required_files_exist():
+    for rel in ("bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/keep_hip.h",
+                "oracle/keep_oracle.py", "tools/make_golden.py", "tests/golden/vit_d24.npz",
+                "tests/golden/bert_l12.npz", "tests/golden/wsi_logic.npz"):
+        assert os.path.exists(os.path.join(ROOT, rel)), rel
+
+
+def test_gpu_side_never_reads_reference():
+    for rel in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(ROOT, rel)).read()
+    for f in py_files(os.path.join(ROOT, "tests")):
+        if os.path.basename(f) == "test_layout.py":
+            continue
+        assert "/root/reference" not in open(f).read(), f

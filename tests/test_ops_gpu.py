@@ -1,0 +1,183 @@
+"""Each HIP kernel against a torch CPU reference of the same operator (through the C ABI)."""
+import math
+
+import pytest
+import torch
+
+from keep_amd.ops import EPI_F16, EPI_GELU_F16, EPI_RESID_F32, EPI_RESID_LS
+
+pytestmark = pytest.mark.gpu
+
+
+def r16(t):
+    return t.to(torch.float16).to(torch.float64)
+
+
+def gelu64(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def rand(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32) * std
+
+
+# ------------------------------------------------------------------ fp16 MFMA GEMM
+GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 4096), (1182, 2304, 768), (333, 4096, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("split", [False, True])
+def test_linear_bias(ops, M, N, K, split):
+    a, w, b = rand(M, K, seed=1), rand(N, K, seed=2, std=0.05), rand(N, seed=3, std=0.1)
+    out = ops.linear(a, w, b, EPI_F16, split).cpu().double()
+    if split:
+        ref = a.double() @ w.double().t() + b.double()
+        assert (out - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    else:
+        ref = r16(a) @ r16(w).t() + b.double()
+        # output is rounded to fp16: half an ulp = 2^-11 relative, plus fp32 accumulation noise
+        assert ((out - ref).abs() <= 5e-4 * ref.abs() + 2e-5 * math.sqrt(K)).all()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_linear_gelu(ops, split):
+    M, N, K = 394, 4096, 1024
+    a, w, b = rand(M, K, seed=4), rand(N, K, seed=5, std=0.03), rand(N, seed=6, std=0.1)
+    out = ops.linear(a, w, b, EPI_GELU_F16, split).cpu().double()
+    if split:
+        ref = gelu64(a.double() @ w.double().t() + b.double())
+        assert (out - ref).abs().max() < 2e-5
+    else:
+        ref = gelu64(r16(a) @ r16(w).t() + b.double())
+        assert ((out - ref).abs() <= 5e-4 * ref.abs() + 1e-4).all()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_linear_layerscale_residual(ops, split):
+    M, N, K = 394, 1024, 4096
+    a, w, b = rand(M, K, seed=7), rand(N, K, seed=8, std=0.02), rand(N, seed=9, std=0.1)
+    ls, resid = torch.rand(N, generator=torch.Generator().manual_seed(10)) * 0.45 + 0.05, rand(M, N, seed=11)
+    out = ops.linear(a, w, b, EPI_RESID_LS, split, ls=ls, resid=resid).cpu().double()
+    A, W = (a.double(), w.double()) if split else (r16(a), r16(w))
+    ref = resid.double() + ls.double() * (A @ W.t() + b.double())
+    assert (out - ref).abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_linear_residual_sum(ops, split):
+    M, N, K = 512, 768, 3072
+    a, w, b, resid = rand(M, K, seed=12), rand(N, K, seed=13, std=0.02), rand(N, seed=14, std=0.1), rand(M, N, seed=15)
+    out = ops.linear(a, w, b, EPI_RESID_F32, split, resid=resid).cpu().double()
+    A, W = (a.double(), w.double()) if split else (r16(a), r16(w))
+    ref = resid.double() + A @ W.t() + b.double()
+    assert (out - ref).abs().max() < 5e-5
+
+
+def test_linear_is_not_transposed(ops):
+    """A = I-like probe with an asymmetric W: catches row/col swaps in the C fragment mapping."""
+    M = N = K = 128
+    a = torch.eye(M, K)
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1024.0
+    out = ops.linear(a, w, torch.zeros(N), EPI_F16, True).cpu()
+    assert (out - w.t()).abs().max() < 1e-3
+
+
+def test_linear_rejects_bad_shapes(ops):
+    with pytest.raises(ValueError):
+        ops.linear(rand(8, 100), rand(128, 100), rand(128))
+    with pytest.raises(ValueError):
+        ops.linear(rand(8, 64), rand(100, 64), rand(100))
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(qkv, B, T, heads, mask, round_ops):
+    D = heads * 64
+    x = qkv.reshape(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4).double()
+    if round_ops:
+        x = x.to(torch.float16).double()
+    q, k, v = x[0], x[1], x[2]
+    s = q @ k.transpose(-1, -2) * 0.125
+    if mask is not None:
+        s = s + (1.0 - mask[:, None, None, :].double()) * -1e30
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize("B,T,heads", [(3, 197, 16), (2, 256, 12), (2, 64, 12), (1, 100, 2), (2, 128, 4), (1, 17, 1)])
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_unmasked(ops, B, T, heads, split):
+    qkv = rand(B * T, 3 * heads * 64, seed=20, std=1.5)
+    out = ops.attention(qkv, B, T, heads, None, split).cpu().double()
+    ref = attn_ref(qkv, B, T, heads, None, not split)
+    tol = 3e-5 if split else 4e-3
+    assert (out - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("T", [256, 40])
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_key_padding_mask(ops, T, split):
+    B, heads = 4, 12
+    qkv = rand(B * T, 3 * heads * 64, seed=21, std=1.5)
+    lens = [T, 9, 1, T // 2]
+    mask = torch.zeros(B, T, dtype=torch.int64)
+    for i, L in enumerate(lens):
+        mask[i, :L] = 1
+    mask[3, 3] = 0      # a hole, not just a prefix
+    out = ops.attention(qkv, B, T, heads, mask, split).cpu().double()
+    ref = attn_ref(qkv, B, T, heads, mask, not split)
+    assert (out - ref).abs().max() < (3e-5 if split else 4e-3)
+
+
+def test_attention_fully_masked_row_is_uniform(ops):
+    """HF adds finfo.min to masked keys: a row with no valid key degenerates to a uniform average."""
+    B, T, heads = 1, 32, 1
+    qkv = rand(B * T, 3 * 64, seed=22)
+    mask = torch.zeros(B, T, dtype=torch.int64)
+    out = ops.attention(qkv, B, T, heads, mask, True).cpu().double()
+    v = qkv[:, 128:192].double()
+    assert (out - v.mean(0, keepdim=True)).abs().max() < 1e-5
+
+
+def test_attention_512_tokens(ops):
+    B, T, heads = 1, 512, 2
+    qkv = rand(B * T, 3 * heads * 64, seed=23)
+    out = ops.attention(qkv, B, T, heads, None, False).cpu().double()
+    assert (out - attn_ref(qkv, B, T, heads, None, True)).abs().max() < 4e-3
+    with pytest.raises(ValueError):
+        ops.attention(rand(600, 192), 1, 600, 1)
+
+
+# ------------------------------------------------------------------ LayerNorm / sgemm / l2norm
+@pytest.mark.parametrize("D,eps", [(1024, 1e-6), (768, 1e-12)])
+def test_layernorm(ops, D, eps):
+    x = rand(301, D, seed=30, std=3.0) + 0.7
+    add = rand(301, D, seed=31)
+    g, b = 1 + rand(D, seed=32, std=0.1), rand(D, seed=33, std=0.1)
+    for a in (None, add):
+        out = ops.layernorm(x, g, b, eps, add=a).cpu()
+        ref = torch.nn.functional.layer_norm((x if a is None else x + a).double(), (D,), g.double(), b.double(), eps)
+        assert (out.double() - ref).abs().max() < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 1024), (5, 3, 768), (300, 64, 768), (130, 7128 // 8, 768)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_sgemm_f32(ops, M, N, K, act):
+    a, b, bias = rand(M, K, seed=40), rand(N, K, seed=41, std=0.05), rand(N, seed=42, std=0.1)
+    out = ops.sgemm(a, b, bias, 0.5, act).cpu().double()
+    ref = 0.5 * (a.double() @ b.double().t()) + bias.double()
+    ref = gelu64(ref) if act == 1 else (torch.tanh(ref) if act == 2 else ref)
+    assert (out - ref).abs().max() < 2e-5
+
+
+def test_sgemm_not_transposed(ops):
+    a = torch.eye(64, 64)
+    b = torch.arange(48 * 64, dtype=torch.float32).reshape(48, 64)
+    assert torch.equal(ops.sgemm(a, b).cpu(), b.t())
+
+
+def test_l2norm(ops):
+    x = rand(37, 768, seed=50).cuda()
+    x[5] = 0
+    ref = torch.nn.functional.normalize(x.cpu(), dim=-1)
+    assert (ops.l2norm_(x).cpu() - ref).abs().max() < 1e-6
