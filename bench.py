@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="tiles per GPU per step")
     ap.add_argument("--precision", default="fp16", choices=["fp16", "strict"])
     ap.add_argument("--pixel-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. gemm_impl=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -116,6 +117,9 @@ def main():
     model = KEEPModel(shape, precision=args.precision)
     model.load_state_dict(sd, strict=True)
     model.to(dev).eval()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, float(v))
     model.reserve(tiles=args.batch)
     log("weights uploaded, workspace reserved")
 

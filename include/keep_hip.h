@@ -83,6 +83,8 @@ int keep_bert_layers(keep_handle* h);
  *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
  *   "max_tiles"       tiles per internal sub-batch of keep_encode_image (default 256)
  *   "max_prompts"     prompts per internal sub-batch of keep_encode_text (default 64)
+ *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256: 256xBN LDS-DMA variant
+ *                     (process-wide kernel selection override, for tests and A/B measurements)
  */
 int keep_set_option(keep_handle* h, const char* name, double value);
 double keep_get_option(keep_handle* h, const char* name);

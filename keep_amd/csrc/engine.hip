@@ -20,6 +20,8 @@
         if (_e != hipSuccess) return (h)->fail(KEEP_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
+
 namespace {
 
 struct WTensor {
@@ -671,6 +673,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
+    else if (n == "gemm_impl") { if (v != 0 && v != 1 && v != 128 && v != 256) return h->fail(KEEP_EINVAL, "gemm_impl %d", v); g_gemm_impl = v; }
     else return h->fail(KEEP_EINVAL, "unknown option %s", name);
     return KEEP_OK;
 }
@@ -681,6 +684,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "strict_blocks") return h->strict_blocks;
     if (n == "max_tiles") return h->max_tiles;
     if (n == "max_prompts") return h->max_prompts;
+    if (n == "gemm_impl") return g_gemm_impl;
     return -1;
 }
 

@@ -16,7 +16,7 @@
 //     ds_write_b128 (8-lane groups) and the ds_read_b128 (16-lane groups) conflict free
 //   * nseg == 3 runs the hi/lo split product  A_hi*W_hi + A_lo*W_hi + A_hi*W_lo  through the same
 //     accumulators (strict precision mode)
-#include "common.h"
+#include "gemm_epilogue.h"
 
 namespace keepk {
 
@@ -123,59 +123,37 @@ void gemm_f16_nt_kernel(GemmParams p) {
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + wm * 64 + j * 32 + frow;
         if (m >= p.M) continue;
-        int64_t orow = m;
-        int prow = 0;
-        if (EPI == EPI_PATCH) {
-            const int b = m / p.patches_per_img;
-            prow = m - b * p.patches_per_img + 1;
-            orow = (int64_t)b * (p.patches_per_img + 1) + prow;
-        }
+        int prow; int64_t orow;
+        gemm_epilogue_row<EPI>(p, m, prow, orow);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * fhi;
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bias[e];
-                const int64_t o = orow * p.N + n;
-                if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
-                    if (EPI == EPI_GELU_F16) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    f16x4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { f16 hh, ll; split_f16(v[e], hh, ll); h[e] = hh; l[e] = ll; }
-                    *reinterpret_cast<f16x4*>(p.out_hi + o) = h;
-                    if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + o) = l;
-                } else if (EPI == EPI_RESID_LS) {
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls + n);
-                    f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r[e] += g[e] * v[e];
-                    *reinterpret_cast<f32x4*>(p.resid + o) = r;
-                } else if (EPI == EPI_PATCH) {
-                    const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += pe[e];
-                    *reinterpret_cast<f32x4*>(p.resid + o) = v;
-                } else {   // EPI_RESID_F32
-                    const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += r[e];
-                    *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+                gemm_epilogue_store<EPI>(p, orow, prow, n, v);
             }
-        }
     }
 }
 
 }  // namespace keepk
 using namespace keepk;
 
+int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s);
+int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
+
 void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s) {
+    int impl = g_gemm_impl;
+    if (impl == 0) {
+        // 256x256 tiles unless the grid would leave the last round of workgroups mostly empty
+        const long mt = (p.M + 255) / 256;
+        if (p.N % 256 == 0 && mt * (p.N / 256) >= 1024) impl = 256;
+        else if (p.N % 128 == 0 && p.M >= 512) impl = 128;
+        else impl = 1;
+    }
+    if (impl != 1 && launch_gemm_f16_v2(p, epi, impl, s) == 0) return;
     dim3 grid(p.N / BN, (p.M + BM - 1) / BM), block(THREADS);
     switch (epi) {
         case EPI_F16:       hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_F16>, grid, block, 0, s, p); break;

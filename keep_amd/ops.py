@@ -36,6 +36,9 @@ class Ops:
         except Exception:
             pass
 
+    def set_option(self, name: str, value: float):
+        _lib.check(self._h, _lib.load().keep_set_option(self._h, name.encode(), float(value)), name)
+
     def _f(self, t: Optional[torch.Tensor]):
         return None if t is None else t.to(self.device, torch.float32).contiguous()
 

@@ -23,12 +23,21 @@ def rand(*shape, seed=0, std=1.0):
 
 
 # ------------------------------------------------------------------ fp16 MFMA GEMM
-GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 4096), (1182, 2304, 768), (333, 4096, 1024)]
+GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 4096), (1182, 2304, 768), (333, 4096, 1024),
+               (2048, 1024, 1024), (1000, 256, 192)]
+
+
+@pytest.fixture(params=[1, 128, 256], ids=["v1_128x128", "v2_256x128", "v2_256x256"])
+def gemm_impl(ops, request):
+    """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile)."""
+    ops.set_option("gemm_impl", request.param)
+    yield request.param
+    ops.set_option("gemm_impl", 0)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("split", [False, True])
-def test_linear_bias(ops, M, N, K, split):
+def test_linear_bias(ops, gemm_impl, M, N, K, split):
     a, w, b = rand(M, K, seed=1), rand(N, K, seed=2, std=0.05), rand(N, seed=3, std=0.1)
     out = ops.linear(a, w, b, EPI_F16, split).cpu().double()
     if split:
@@ -41,7 +50,7 @@ def test_linear_bias(ops, M, N, K, split):
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_linear_gelu(ops, split):
+def test_linear_gelu(ops, gemm_impl, split):
     M, N, K = 394, 4096, 1024
     a, w, b = rand(M, K, seed=4), rand(N, K, seed=5, std=0.03), rand(N, seed=6, std=0.1)
     out = ops.linear(a, w, b, EPI_GELU_F16, split).cpu().double()
@@ -54,7 +63,7 @@ def test_linear_gelu(ops, split):
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_linear_layerscale_residual(ops, split):
+def test_linear_layerscale_residual(ops, gemm_impl, split):
     M, N, K = 394, 1024, 4096
     a, w, b = rand(M, K, seed=7), rand(N, K, seed=8, std=0.02), rand(N, seed=9, std=0.1)
     ls, resid = torch.rand(N, generator=torch.Generator().manual_seed(10)) * 0.45 + 0.05, rand(M, N, seed=11)
@@ -65,7 +74,7 @@ def test_linear_layerscale_residual(ops, split):
 
 
 @pytest.mark.parametrize("split", [False, True])
-def test_linear_residual_sum(ops, split):
+def test_linear_residual_sum(ops, gemm_impl, split):
     M, N, K = 512, 768, 3072
     a, w, b, resid = rand(M, K, seed=12), rand(N, K, seed=13, std=0.02), rand(N, seed=14, std=0.1), rand(M, N, seed=15)
     out = ops.linear(a, w, b, EPI_RESID_F32, split, resid=resid).cpu().double()
@@ -74,13 +83,23 @@ def test_linear_residual_sum(ops, split):
     assert (out - ref).abs().max() < 5e-5
 
 
-def test_linear_is_not_transposed(ops):
+def test_linear_is_not_transposed(ops, gemm_impl):
     """A = I-like probe with an asymmetric W: catches row/col swaps in the C fragment mapping."""
-    M = N = K = 128
+    M = N = K = 256
     a = torch.eye(M, K)
     w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1024.0
     out = ops.linear(a, w, torch.zeros(N), EPI_F16, True).cpu()
     assert (out - w.t()).abs().max() < 1e-3
+
+
+def test_gelu_epilogue_accuracy_sweep(ops, gemm_impl):
+    """The branch-free erf in the epilogue: drive acc+bias over [-6, 6] through an identity GEMM."""
+    M, N, K = 256, 256, 256
+    a = torch.eye(M, K)
+    xs = torch.linspace(-6, 6, N * K).reshape(N, K)
+    out = ops.linear(a, xs, torch.zeros(N), EPI_GELU_F16, True).cpu().double()     # split: fp32-class output
+    ref = gelu64(xs.double()).t()
+    assert (out - ref).abs().max() < 2e-6
 
 
 def test_linear_rejects_bad_shapes(ops):
