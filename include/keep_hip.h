@@ -144,6 +144,9 @@ int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const fl
 int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* bias, int64_t M, int64_t N,
                   int64_t K, float scale, int act, float* out, void* stream);
 int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream);
+/* diagnostics: with option "gemm_dbg"=1 every GEMM launch records, per workgroup, four shader-clock
+ * stamps [start, first K tile landed, main loop end, end]; this copies them to host memory. */
+int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes);
 
 #ifdef __cplusplus
 }

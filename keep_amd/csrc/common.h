@@ -67,6 +67,9 @@ struct GemmParams {
     float* out_f32;                       // EPI_RESID_F32
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
     int patches_per_img;                  // EPI_PATCH: 196
+    int stagger_cycles;                   // first-round workgroup b sleeps b/256 * stagger_cycles (phase-spreads the epilogues)
+    long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
+    int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
 };
 
 void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);

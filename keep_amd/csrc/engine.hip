@@ -20,6 +20,9 @@
         if (_e != hipSuccess) return (h)->fail(KEEP_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+extern int g_gemm_ablate;
+extern long long* g_gemm_dbg;
+extern int g_gemm_stagger_pct;
 extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
 
 namespace {
@@ -673,6 +676,12 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
+    else if (n == "gemm_ablate") { g_gemm_ablate = v; }
+    else if (n == "gemm_stagger_pct") { g_gemm_stagger_pct = v; }
+    else if (n == "gemm_dbg") {
+        if (v && !g_gemm_dbg) { HIPCHK(h, hipMalloc(&g_gemm_dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(g_gemm_dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
+        if (!v && g_gemm_dbg) { hipFree(g_gemm_dbg); g_gemm_dbg = nullptr; }
+    }
     else if (n == "gemm_impl") { if (v != 0 && v != 1 && v != 128 && v != 256) return h->fail(KEEP_EINVAL, "gemm_impl %d", v); g_gemm_impl = v; }
     else return h->fail(KEEP_EINVAL, "unknown option %s", name);
     return KEEP_OK;
@@ -896,6 +905,13 @@ int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* b
     g.scale = scale; g.act = act;
     if (launch_sgemm_f32(g, (hipStream_t)stream)) return h->fail(KEEP_EUNSUPPORTED, "sgemm needs K%%16==0");
     return check_launch(h, "op_sgemm");
+}
+
+int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes) {
+    if (!h || !host_dst || !g_gemm_dbg || bytes > (int64_t)65536 * 4 * 8) return KEEP_EINVAL;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(host_dst, g_gemm_dbg, bytes, hipMemcpyDeviceToHost));
+    return KEEP_OK;
 }
 
 int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream) {

@@ -125,16 +125,17 @@ void gemm_f16_nt_kernel(GemmParams p) {
         if (m >= p.M) continue;
         int prow; int64_t orow;
         gemm_epilogue_row<EPI>(p, m, prow, orow);
+        int nn[8];
+        f32x4 vv[8];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * rg + 4 * fhi;
-                f32x4 v;
+                nn[i * 4 + rg] = n0 + wn * 64 + i * 32 + 8 * rg + 4 * fhi;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-                gemm_epilogue_store<EPI>(p, orow, prow, n, v);
+                for (int e = 0; e < 4; ++e) vv[i * 4 + rg][e] = acc[i][j][rg * 4 + e];
             }
+        gemm_epilogue_batch<EPI, 8>(p, orow, prow, nn, vv);
     }
 }
 
@@ -142,9 +143,17 @@ void gemm_f16_nt_kernel(GemmParams p) {
 using namespace keepk;
 
 int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s);
+int g_gemm_ablate = 0;
+long long* g_gemm_dbg = nullptr;
+int g_gemm_stagger_pct = 0;   // stagger span as % of the estimated tile time (0 = off)
 int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
 
-void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s) {
+void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
+    GemmParams p = p_in;
+    p.ablate = g_gemm_ablate;
+    p.dbg = g_gemm_dbg;
+    // estimated 256x256 tile time: ~2000 cycles per 32-deep K step + ~10k cycles of prologue/epilogue
+    p.stagger_cycles = (int)((2000LL * (p.K / 32) * p.nseg + 10000) * g_gemm_stagger_pct / 100);
     int impl = g_gemm_impl;
     if (impl == 0) {
         // 256x256 tiles unless the grid would leave the last round of workgroups mostly empty

@@ -9,18 +9,27 @@
 //     VGPR round trip).  The DMA writes LDS linearly (wave base + lane*16), so the XOR swizzle that
 //     makes ds_read_b128 conflict-free is applied to the per-lane GLOBAL source address instead:
 //     LDS slot (row, s) holds logical 16-B chunk s ^ ((row>>1)&7) of that row
-//   * two LDS buffers (2 x (256 + BN) x 128 B); the DMA for K-tile t+1 is issued before the MFMAs
-//     of tile t and drained (vmcnt(0)) at the single barrier that ends the step
+//   * a ring of NSTAGE LDS buffers of BK = 32 (256 + BN rows x 64 B each).  One K tile in flight is
+//     latency-bound (a 64 KiB DMA burst takes ~1.9 us to land, measured: that alone set the step
+//     time), so NSTAGE-1 tiles are kept in flight: the wait before using tile s is a COUNTED
+//     s_waitcnt vmcnt(G*(NSTAGE-2)) followed by a raw s_barrier (a __syncthreads() would drain the
+//     DMA queue to zero), and the DMA for tile s+NSTAGE-1 is issued right after that barrier
 //   * nseg == 3: hi/lo split product through the same accumulators (strict precision)
 #include "gemm_epilogue.h"
 
 namespace keepk {
 
-constexpr int V2_BM = 256, V2_BK = 64, V2_THREADS = 512;
+constexpr int V2_BM = 256, V2_BK = 32, V2_THREADS = 512, V2_NSTAGE = 4;
 
-__device__ __forceinline__ int v2_lds_off(int row, int chunk) {
-    return row * V2_BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+// 64-byte LDS rows (4 slots of 16 B): slot ^= (row>>2)&3 spreads any 16 consecutive rows over all
+// 16 distinct (row&3, slot) bank positions -> conflict-free ds_read_b128
+__device__ int g_swz_mask_dummy;
+__device__ __forceinline__ int v2_swz(int row, int mask = 3) { return (row >> 2) & mask; }
+__device__ __forceinline__ int v2_lds_off(int row, int chunk, int mask = 3) {
+    return row * V2_BK + ((chunk ^ v2_swz(row, mask)) << 3);
 }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -31,8 +40,11 @@ void gemm_f16_v2_kernel(GemmParams p) {
     constexpr int BM = V2_BM, BK = V2_BK;
     constexpr int TM = BM / WM / 32;            // MFMA tiles per wave along m
     constexpr int TN = BN / WN / 32;            // along n
-    constexpr int A_ROUNDS = BM * 8 / V2_THREADS;   // 16-B slots per thread per K tile
-    constexpr int B_ROUNDS = BN * 8 / V2_THREADS;
+    constexpr int SLOTS = BK / 8;                    // 16-B slots per LDS row
+    constexpr int A_ROUNDS = BM * SLOTS / V2_THREADS;   // DMA instructions per thread per K tile
+    constexpr int B_ROUNDS = BN * SLOTS / V2_THREADS;
+    constexpr int G = A_ROUNDS + B_ROUNDS;
+    constexpr int NSTAGE = V2_NSTAGE;
     constexpr int BUF_ELEMS = (BM + BN) * BK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f16* lds = reinterpret_cast<f16*>(smem_raw);
@@ -43,24 +55,45 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     // tile coordinates: consecutive workgroups share the A panel (same m tile, different n tile)
+    // XCD-aware, L2-blocked tile order.  Hardware places workgroup b on XCD b % 8 (used for speed only,
+    // never for correctness).  Each XCD gets a contiguous run of the tile sequence (bijective for any
+    // grid size), and the sequence itself walks the tile grid in column bands of 4 n-tiles, m fastest
+    // after n: the ~32 workgroups resident on one XCD then cover an ~8 x 4 patch of tiles (each A
+    // panel shared by 4 CUs, each W panel by 8) and the band's W panels stay in that XCD's 4 MiB L2
+    // from one round to the next.
     const int ntn = p.N / BN;
-    const int bid = blockIdx.x;
-    const int m0 = (bid / ntn) * BM;
-    const int n0 = (bid % ntn) * BN;
+    const int mtn = (p.M + BM - 1) / BM;
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    constexpr int BW = 4;
+    const int full_tiles = (ntn / BW) * BW * mtn;
+    int tm, tn;
+    if (t < full_tiles) {
+        const int band = t / (mtn * BW), rr = t - band * (mtn * BW);
+        tm = rr / BW; tn = band * BW + (rr - tm * BW);
+    } else {
+        const int remw = ntn % BW, rr = t - full_tiles;
+        tm = rr / remw; tn = (ntn / BW) * BW + (rr - tm * remw);
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
 
+    const int swz_mask = (p.ablate & 4) ? 0 : 3;     // diagnostics: ablate&4 disables the swizzle on both sides
     // ---- DMA source offsets (elements) per round; LDS slot L = round*512 + tid -> row L>>3, slot L&7
     int64_t a_off[A_ROUNDS], w_off[B_ROUNDS];
 #pragma unroll
     for (int r = 0; r < A_ROUNDS; ++r) {
         const int L = r * V2_THREADS + tid;
-        const int row = L >> 3, c = (L & 7) ^ ((row >> 1) & 7);
+        const int row = L / SLOTS, c = (L % SLOTS) ^ v2_swz(row, swz_mask);
         int am = m0 + row; am = am < p.M ? am : p.M - 1;
         a_off[r] = (int64_t)am * p.K + c * 8;
     }
 #pragma unroll
     for (int r = 0; r < B_ROUNDS; ++r) {
         const int L = r * V2_THREADS + tid;
-        const int row = L >> 3, c = (L & 7) ^ ((row >> 1) & 7);
+        const int row = L / SLOTS, c = (L % SLOTS) ^ v2_swz(row, swz_mask);
         w_off[r] = (int64_t)(n0 + row) * p.K + c * 8;
     }
 
@@ -90,55 +123,181 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(0, 0);
-    __syncthreads();
-
-    const int frow = lane & 31, fhi = lane >> 5;
-    for (int s = 0; s < steps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < steps) stage(s + 1, buf ^ 1);
-        const f16* sa = lds + buf * BUF_ELEMS;
-        const f16* sw = sa + BM * BK;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f16x8 fw[TN], fa[TM];
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-                fw[i] = *reinterpret_cast<const f16x8*>(sw + v2_lds_off(wn * (TN * 32) + i * 32 + frow, ks * 2 + fhi));
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-                fa[j] = *reinterpret_cast<const f16x8*>(sa + v2_lds_off(wm * (TM * 32) + j * 32 + frow, ks * 2 + fhi));
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();      // drains the DMA of tile s+1 (vmcnt(0)) and fences the reads of tile s
+    long long t_start = 0, t_first = 0, t_loop = 0;
+    if (p.dbg) t_start = __builtin_readcyclecounter();
+    // Phase spreading.  All workgroups of a round start together and take the same time, so without
+    // this every CU reaches its epilogue at the same moment: the round's whole output (e.g. 128 MB of
+    // fp32 residual read-modify-write) hits HBM in one burst while every MFMA pipe idles (measured:
+    // ~25 us of a 56 us tile).  Delaying first-round workgroup b by b/256 of a tile time spreads the
+    // epilogues evenly; later rounds inherit the spread.  Speed only: any dispatch order is correct.
+    if (p.stagger_cycles > 0 && blockIdx.x < 256) {
+        const long long t0 = __builtin_readcyclecounter();
+        const long long want = ((long long)p.stagger_cycles * (long long)blockIdx.x) >> 8;
+        while (__builtin_readcyclecounter() - t0 < want) __builtin_amdgcn_s_sleep(32);
     }
 
+    // ---- software-pipelined main loop -------------------------------------------------------------
+    // Per K tile (32 deep) a wave runs two groups of TN*TM MFMAs, on fragment sets R0 (k 0..15) and R1
+    // (k 16..31).  The single barrier of a step sits BETWEEN the two groups:
+    //     MFMA(R0[s]) ; vmcnt: tile s+1 landed ; lgkmcnt(0) ; barrier ;
+    //     DMA tile s+NSTAGE -> stage s%NSTAGE ; read R0[s+1] ; MFMA(R1[s]) ; read R1[s+1]
+    // so the LDS reads for the next group and the DMA issue run under the other group's MFMAs, and a
+    // wave waiting at the barrier waits while its SIMD partner still feeds the matrix pipe.
+    const int frow = lane & 31, fhi = lane >> 5;
+    f16x8 fw0[TN], fa0[TM], fw1[TN], fa1[TM];
+    auto read_frags = [&](int st, int ks, f16x8 (&fw)[TN], f16x8 (&fa)[TM]) {
+        const f16* sa = lds + st * BUF_ELEMS;
+        const f16* sw = sa + BM * BK;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            fw[i] = *reinterpret_cast<const f16x8*>(sw + v2_lds_off(wn * (TN * 32) + i * 32 + frow, ks * 2 + fhi, swz_mask));
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            fa[j] = *reinterpret_cast<const f16x8*>(sa + v2_lds_off(wm * (TM * 32) + j * 32 + frow, ks * 2 + fhi, swz_mask));
+    };
+    auto mfma_group = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+        if (t < steps) stage(t, t);
+    if (steps >= NSTAGE - 1) wait_vmcnt<G * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (p.dbg) t_first = __builtin_readcyclecounter();
+    if (NSTAGE - 1 < steps) stage(NSTAGE - 1, NSTAGE - 1);
+    read_frags(0, 0, fw0, fa0);
+    read_frags(0, 1, fw1, fa1);
+
+    // steady state: every step but the last NSTAGE-1 has a full ring in flight
+    int s = 0;
+    for (; s < steps - (NSTAGE - 1); ++s) {
+        mfma_group(fw0, fa0);
+        wait_vmcnt<G * (NSTAGE - 2)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + NSTAGE < steps) stage(s + NSTAGE, s % NSTAGE);
+        read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
+        mfma_group(fw1, fa1);
+        read_frags((s + 1) % NSTAGE, 1, fw1, fa1);
+    }
+    // drain: fewer tiles in flight, wait for everything that is left
+    for (; s < steps - 1; ++s) {
+        mfma_group(fw0, fa0);
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
+        mfma_group(fw1, fa1);
+        read_frags((s + 1) % NSTAGE, 1, fw1, fa1);
+    }
+    mfma_group(fw0, fa0);
+    mfma_group(fw1, fa1);
+
+    if (p.dbg) t_loop = __builtin_readcyclecounter();
+
+    // ---- epilogue through LDS ---------------------------------------------------------------------
+    // An MFMA C fragment gives a lane 4 consecutive n of ONE m, so storing straight from registers makes
+    // every store instruction touch 32 different rows (measured 16k-33k cycles per tile, bound by the
+    // address path, not by bytes).  Each wave instead bounces one 32(m) x WN_COLS(n) slab at a time through
+    // its private 16 KiB of the (now idle) LDS ring and leaves with whole 128/256-byte row segments.
+    __syncthreads();
+    constexpr int WN_COLS = TN * 32;                 // 64 for the 256x256 variant
+    constexpr int PITCH = WN_COLS + 4;               // fp32 elements; +4 keeps ds_write_b128 conflict free
+    float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * PITCH + 64);
+    constexpr bool F16_OUT = (EPI == EPI_F16 || EPI == EPI_GELU_F16);
+    constexpr int CPL = F16_OUT ? 8 : 4;             // columns per lane on the way out
+    constexpr int LPR = WN_COLS / CPL;               // lanes per row
+    constexpr int RPI = 64 / LPR;                    // rows per instruction
+    const int ocol = (lane % LPR) * CPL;
+    const int orow_in = lane / LPR;
+    const int ncol = n0 + wn * WN_COLS + ocol;
+    f32x4 bias4[CPL / 4], ls4[CPL / 4];
+#pragma unroll
+    for (int c = 0; c < CPL / 4; ++c) {
+        bias4[c] = *reinterpret_cast<const f32x4*>(p.bias + ncol + c * 4);
+        if (EPI == EPI_RESID_LS) ls4[c] = *reinterpret_cast<const f32x4*>(p.ls + ncol + c * 4);
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * (TM * 32) + j * 32 + frow;
-        if (m >= p.M) continue;
-        int prow; int64_t orow;
-        gemm_epilogue_row<EPI>(p, m, prow, orow);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wn * (TN * 32) + i * 32 + 8 * rg + 4 * fhi;
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-                gemm_epilogue_store<EPI>(p, orow, prow, n, v);
+                *reinterpret_cast<f32x4*>(slab + frow * PITCH + i * 32 + 8 * rg + 4 * fhi) = v;
             }
+        const int mbase = m0 + wm * (TM * 32) + j * 32;
+        if (F16_OUT) {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int r = it * RPI + orow_in;
+                const int m = mbase + r;
+                f32x4 x0 = *reinterpret_cast<const f32x4*>(slab + r * PITCH + ocol);
+                f32x4 x1 = *reinterpret_cast<const f32x4*>(slab + r * PITCH + ocol + 4);
+                f16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = x0[e] + bias4[0][e], b = x1[e] + bias4[CPL / 4 - 1][e];
+                    if (EPI == EPI_GELU_F16) { a = gelu_fast(a); b = gelu_fast(b); }
+                    f16 hh, ll;
+                    split_f16(a, hh, ll); h[e] = hh; l[e] = ll;
+                    split_f16(b, hh, ll); h[4 + e] = hh; l[4 + e] = ll;
+                }
+                if (m < p.M) {
+                    const int64_t o = (int64_t)m * p.N + ncol;
+                    *reinterpret_cast<f16x8*>(p.out_hi + o) = h;
+                    if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = l;
+                }
+            }
+        } else {
+            // issue every global read of the slab first, then the math and the stores
+            f32x4 res[32 / RPI];
+            int64_t oo[32 / RPI];
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int m = mbase + it * RPI + orow_in;
+                const int mc = m < p.M ? m : p.M - 1;
+                int prow; int64_t orow;
+                gemm_epilogue_row<EPI>(p, mc, prow, orow);
+                oo[it] = orow * p.N + ncol;
+                if (EPI == EPI_PATCH) res[it] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + ncol);
+                else res[it] = *reinterpret_cast<const f32x4*>(p.resid + oo[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int r = it * RPI + orow_in;
+                f32x4 x = *reinterpret_cast<const f32x4*>(slab + r * PITCH + ocol);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] += bias4[0][e];
+                    x[e] = (EPI == EPI_RESID_LS) ? res[it][e] + ls4[0][e] * x[e] : res[it][e] + x[e];
+                }
+                if (mbase + r < p.M) {
+                    float* dst = (EPI == EPI_RESID_F32) ? p.out_f32 : p.resid;
+                    *reinterpret_cast<f32x4*>(dst + oo[it]) = x;
+                }
+            }
+        }
+    }
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            long long* d = p.dbg + (size_t)blockIdx.x * 4;
+            d[0] = t_start; d[1] = t_first; d[2] = t_loop; d[3] = __builtin_readcyclecounter();
+        }
     }
 }
 
 template <int BN, int WM, int WN>
 int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
-    constexpr size_t lds_bytes = 2 * (size_t)(V2_BM + BN) * V2_BK * sizeof(f16);
+    constexpr size_t lds_bytes = (size_t)V2_NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
     static bool attr_set = false;
     if (!attr_set) {
 #define KEEP_SET_ATTR(E) if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_v2_kernel<BN, WM, WN, E>), \

@@ -39,6 +39,14 @@ class Ops:
     def set_option(self, name: str, value: float):
         _lib.check(self._h, _lib.load().keep_set_option(self._h, name.encode(), float(value)), name)
 
+    def debug_timeline(self, nblocks: int):
+        """[nblocks,4] int64 shader-clock stamps of the last GEMM launch (needs option gemm_dbg=1)."""
+        import numpy as np
+        buf = np.zeros((nblocks, 4), dtype=np.int64)
+        rc = _lib.load().keep_debug_read(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+        _lib.check(self._h, rc, "debug_read")
+        return buf
+
     def _f(self, t: Optional[torch.Tensor]):
         return None if t is None else t.to(self.device, torch.float32).contiguous()
 
