@@ -34,46 +34,58 @@ __device__ __forceinline__ unsigned sel4(const uint4& x, int i) {
     return i == 0 ? x.x : (i == 1 ? x.y : (i == 2 ? x.z : x.w));
 }
 
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+
+// Stage one head's K (row-major, swizzled slots) and V^T (feature-major) into LDS.
+//   K   : LDS-DMA (global_load_lds, 16 B per lane, no registers): the LDS image is linear in the slot
+//         index, so the slot swizzle is applied to the per-lane SOURCE address.
+//   V^T : needs a transpose, so it goes through registers -- but ALL loads are issued before the first
+//         LDS write (the first version looped load->write and paid one memory round trip per pass:
+//         72 % of the kernel's wave-cycles were s_waitcnt).
+// Rows >= ntok are filled with a copy of the last valid row (finite values); their scores are masked
+// with -inf, so P is exactly 0 there and 0 * finite contributes nothing.
 template <int NT>
 __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok, int D3, int koff, int voff,
-                                         f16* sK, f16* sVt, int tid) {
-    // Branch-free staging: out-of-range work items are clamped onto the last valid item (they rewrite
-    // identical bytes) and rows >= ntok are loaded from row ntok-1 and then zeroed with a select.
+                                         f16* sK, f16* sVt, int tid, int wave) {
     constexpr int NKP = NT * 16;
     constexpr int VS = att_vs(NT);
     constexpr int NPAIR = att_kp2(NT) / 2;
     constexpr int K_ITEMS = NKP * 8, V_ITEMS = NPAIR * 8;
     constexpr int K_IT = (K_ITEMS + ATT_THREADS - 1) / ATT_THREADS;
     constexpr int V_IT = (V_ITEMS + ATT_THREADS - 1) / ATT_THREADS;
-    const uint4 zero = {0, 0, 0, 0};
-#pragma unroll 2
+#pragma unroll
     for (int it = 0; it < K_IT; ++it) {
-        int idx = tid + it * ATT_THREADS;
-        idx = idx < K_ITEMS ? idx : K_ITEMS - 1;
-        const int row = idx >> 3, c = idx & 7;
-        const int rc = row < ntok ? row : ntok - 1;
-        uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)rc * D3 + koff + c * 8);
-        v = row < ntok ? v : zero;
-        *reinterpret_cast<uint4*>(sK + row * HD + ((c ^ ((row >> 1) & 7)) << 3)) = v;
+        const int L = tid + it * ATT_THREADS;              // LDS slot index; K_ITEMS is a multiple of 128,
+        if (L < K_ITEMS) {                                 // so this predicate is wave-uniform
+            const int row = L >> 3, c = (L & 7) ^ ((row >> 1) & 7);
+            const int rc = row < ntok ? row : ntok - 1;
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(base + (int64_t)rc * D3 + koff + c * 8),
+                                             (att_lptr_t)(sK + (it * ATT_THREADS + wave * 64) * 8), 16, 0, 0);
+        }
     }
-#pragma unroll 2
+    uint4 va[V_IT], vb[V_IT];
+#pragma unroll
+    for (int it = 0; it < V_IT; ++it) {
+        int idx = tid + it * ATT_THREADS;
+        idx = idx < V_ITEMS ? idx : V_ITEMS - 1;           // clamped duplicates rewrite identical bytes
+        const int kp = idx >> 3, c = idx & 7;
+        const int r0 = 2 * kp < ntok ? 2 * kp : ntok - 1, r1 = 2 * kp + 1 < ntok ? 2 * kp + 1 : ntok - 1;
+        va[it] = *reinterpret_cast<const uint4*>(base + (int64_t)r0 * D3 + voff + c * 8);
+        vb[it] = *reinterpret_cast<const uint4*>(base + (int64_t)r1 * D3 + voff + c * 8);
+    }
+#pragma unroll
     for (int it = 0; it < V_IT; ++it) {
         int idx = tid + it * ATT_THREADS;
         idx = idx < V_ITEMS ? idx : V_ITEMS - 1;
         const int kp = idx >> 3, c = idx & 7;
-        const int k0 = 2 * kp, k1 = 2 * kp + 1;
-        const int r0 = k0 < ntok ? k0 : ntok - 1, r1 = k1 < ntok ? k1 : ntok - 1;
-        uint4 a = *reinterpret_cast<const uint4*>(base + (int64_t)r0 * D3 + voff + c * 8);
-        uint4 b = *reinterpret_cast<const uint4*>(base + (int64_t)r1 * D3 + voff + c * 8);
-        a = k0 < ntok ? a : zero;
-        b = k1 < ntok ? b : zero;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int e = (r + c) & 7;                  // rotate so the 8 lanes of a key pair hit 8 banks
-            const unsigned wa = sel4(a, e >> 1), wb = sel4(b, e >> 1);
+            const unsigned wa = sel4(va[it], e >> 1), wb = sel4(vb[it], e >> 1);
             const int sh = (e & 1) * 16;
             const unsigned packed = ((wa >> sh) & 0xffffu) | (((wb >> sh) & 0xffffu) << 16);
-            *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * VS + k0) = packed;
+            *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * VS + 2 * kp) = packed;
         }
     }
 }
@@ -91,7 +103,8 @@ void attention_kernel(AttnParams p) {
     f16* sKl = reinterpret_cast<f16*>(sBias + NKP);
     f16* sVtl = sKl + NKP * HD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / p.heads, h = blockIdx.x - b * p.heads;
     const int ntok = p.ntok;
     const int D = p.heads * HD, D3 = 3 * D;
@@ -99,8 +112,8 @@ void attention_kernel(AttnParams p) {
     const f16* base_hi = p.qkv_hi + tok0 * D3;
     const f16* base_lo = SPLIT ? p.qkv_lo + tok0 * D3 : nullptr;
 
-    stage_kv<NT>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid);
-    if (SPLIT) stage_kv<NT>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid);
+    stage_kv<NT>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
+    if (SPLIT) stage_kv<NT>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
     for (int k = tid; k < NKP; k += ATT_THREADS) {
         float bias = 0.f;
         if (k >= ntok) bias = -INFINITY;
@@ -111,15 +124,24 @@ void attention_kernel(AttnParams p) {
 
     const int qi = lane & 15, g = lane >> 4;
     const int nqt = (ntok + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
-        const int q = qt * 16 + qi;
-        const int qc = q < ntok ? q : ntok - 1;
-        f16x8 qf[2], ql[2];
+    // Q fragments of the next query tile are fetched while the current one is computed
+    f16x8 qn[2], qln[2];
+    auto load_q = [&](int qt) {
+        int q = qt * 16 + qi;
+        q = q < ntok ? q : ntok - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = *reinterpret_cast<const f16x8*>(base_hi + (int64_t)qc * D3 + h * HD + ks * 32 + g * 8);
-            if (SPLIT) ql[ks] = *reinterpret_cast<const f16x8*>(base_lo + (int64_t)qc * D3 + h * HD + ks * 32 + g * 8);
+            qn[ks] = *reinterpret_cast<const f16x8*>(base_hi + (int64_t)q * D3 + h * HD + ks * 32 + g * 8);
+            if (SPLIT) qln[ks] = *reinterpret_cast<const f16x8*>(base_lo + (int64_t)q * D3 + h * HD + ks * 32 + g * 8);
         }
+    };
+    if (wave < nqt) load_q(wave);
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + qi;
+        f16x8 qf[2], ql[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; if (SPLIT) ql[ks] = qln[ks]; }
+        if (qt + 4 < nqt) load_q(qt + 4);
         // The K / V^T fragment reads do not depend on the query tile; without the compiler barriers
         // below LICM hoists ALL of them out of the qt loop (hundreds of VGPRs -> scratch spills).
         // Each loop is software-pipelined one step deep by hand instead.

@@ -5,38 +5,30 @@
 
 namespace keepk {
 
-// Branch-free single-precision erf (libm erff is ~40+ VALU ops with divergent branches, and it sits in
-// the epilogue of the largest GEMM).  Two Chebyshev-fitted pieces evaluated unconditionally and selected:
-//   |x| <= 0.921875 : erf(x) = x * P6(x^2)
-//   |x| >  0.921875 : erf(x) = sign(x) * (1 - exp(-Q9(min(|x|, 4))))      Q(t) = -log(erfc(t))
-// max |erf_fast - erf| = 1.13e-7 over [-6, 6] (fit + fp32 Horner emulation in tools/fit_erf.py); the GELU
-// built on it is checked against float64 erf in tests/test_ops_gpu.py.
-__device__ __forceinline__ float erf_fast(float x) {
-    const float t = fminf(fabsf(x), 4.0f);
-    const float s = x * x;
-    float p = 8.392696327064186e-05f;
-    p = fmaf(p, s, -0.0008148506167344749f);
-    p = fmaf(p, s, 0.005201591644436121f);
-    p = fmaf(p, s, -0.026859646663069725f);
-    p = fmaf(p, s, 0.11283700168132782f);
-    p = fmaf(p, s, -0.37612634897232056f);
-    p = fmaf(p, s, 1.128379225730896f);
-    const float r1 = p * x;
-    float q = 3.990486874272392e-08f;
-    q = fmaf(q, t, -2.4969324385892833e-06f);
-    q = fmaf(q, t, 5.4058713431004435e-05f);
-    q = fmaf(q, t, -0.0006388962501659989f);
-    q = fmaf(q, t, 0.00489716324955225f);
-    q = fmaf(q, t, -0.02670992538332939f);
-    q = fmaf(q, t, 0.11046823859214783f);
-    q = fmaf(q, t, 0.631505012512207f);
-    q = fmaf(q, t, 1.1303812265396118f);
-    q = fmaf(q, t, -0.00034889878588728607f);
-    const float r2 = copysignf(1.0f - __expf(-q), x);
-    return fabsf(x) <= 0.921875f ? r1 : r2;
-}
+// Branch-free exact-GELU for the fc1 epilogue (libm erff is ~40+ VALU ops with divergent branches and
+// sat in the epilogue of the largest GEMM: 13k of 78k cycles per tile).  With a = min(|x|, 6):
+//     Phi(-a) = 0.5 * erfc(a / sqrt2) = 2^-P(a)          P: degree-11 polynomial, P(0) = 1
+//     gelu(x) = x * (x < 0 ? u : 1 - u),   u = 2^-P(|x|)
+// One polynomial, one v_exp_f32, no cancellation for x < 0.  Fitted in tools/fit_gelu.py (weighted
+// least squares in absolute-Phi error, fp32 Horner emulation): max |gelu_fast - gelu| = 3.8e-7 over
+// [-8, 8] (the fp32 rounding of x*Phi itself); checked on the GPU against float64 erf in
+// tests/test_ops_gpu.py::test_gelu_epilogue_accuracy_sweep.
 __device__ __forceinline__ float gelu_fast(float x) {
-    return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    const float a = fminf(fabsf(x), 6.0f);
+    float p = -3.594286202e-09f;
+    p = fmaf(p, a, 1.257803746e-07f);
+    p = fmaf(p, a, -1.958191660e-06f);
+    p = fmaf(p, a, 1.778304431e-05f);
+    p = fmaf(p, a, -1.016299357e-04f);
+    p = fmaf(p, a, 3.363231954e-04f);
+    p = fmaf(p, a, -7.651424676e-05f);
+    p = fmaf(p, a, -6.888056640e-03f);
+    p = fmaf(p, a, 5.241813138e-02f);
+    p = fmaf(p, a, 4.592245221e-01f);
+    p = fmaf(p, a, 1.151104093e+00f);
+    p = fmaf(p, a, 1.0f);
+    const float u = __builtin_amdgcn_exp2f(-p);
+    return x * (x < 0.f ? u : 1.0f - u);
 }
 
 template <int EPI>

@@ -156,9 +156,7 @@ void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     p.stagger_cycles = (int)((2000LL * (p.K / 32) * p.nseg + 10000) * g_gemm_stagger_pct / 100);
     int impl = g_gemm_impl;
     if (impl == 0) {
-        // 256x256 tiles unless the grid would leave the last round of workgroups mostly empty
-        const long mt = (p.M + 255) / 256;
-        if (p.N % 256 == 0 && mt * (p.N / 256) >= 1024) impl = 256;
+        if (p.N % 256 == 0 && p.M >= 1024) impl = 256;
         else if (p.N % 128 == 0 && p.M >= 512) impl = 128;
         else impl = 1;
     }

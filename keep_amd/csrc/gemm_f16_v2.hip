@@ -155,13 +155,22 @@ void gemm_f16_v2_kernel(GemmParams p) {
         for (int j = 0; j < TM; ++j)
             fa[j] = *reinterpret_cast<const f16x8*>(sa + v2_lds_off(wm * (TM * 32) + j * 32 + frow, ks * 2 + fhi, swz_mask));
     };
-    auto mfma_group = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) {
+    // MFMA group split in a head (first row of tiles) and a tail, so that the LDS reads / DMA issue
+    // for the NEXT group can be pinned between them: they then never sit in front of a wait.
+    auto mfma_head = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int j = 0; j < TM; ++j)
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[0], fa[j], acc[0][j], 0, 0, 0);
+    };
+    auto mfma_tail = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) {
+#pragma unroll
+        for (int i = 1; i < TN; ++i)
 #pragma unroll
             for (int j = 0; j < TM; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
     };
+    auto mfma_group = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) { mfma_head(fw, fa); mfma_tail(fw, fa); };
+#define KEEP_PIN() __builtin_amdgcn_sched_barrier(0)
 
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
@@ -171,32 +180,54 @@ void gemm_f16_v2_kernel(GemmParams p) {
     if (p.dbg) t_first = __builtin_readcyclecounter();
     if (NSTAGE - 1 < steps) stage(NSTAGE - 1, NSTAGE - 1);
     read_frags(0, 0, fw0, fa0);
-    read_frags(0, 1, fw1, fa1);
 
     // steady state: every step but the last NSTAGE-1 has a full ring in flight
     int s = 0;
     for (; s < steps - (NSTAGE - 1); ++s) {
-        mfma_group(fw0, fa0);
+        // group 0 on R0[s]; R1[s] (same stage, already landed) is fetched under it
+        mfma_head(fw0, fa0);
+        KEEP_PIN();
+        read_frags(s % NSTAGE, 1, fw1, fa1);
+        KEEP_PIN();
+        mfma_tail(fw0, fa0);
+        KEEP_PIN();
         wait_vmcnt<G * (NSTAGE - 2)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        KEEP_PIN();
+        // group 1 on R1[s]; DMA for tile s+NSTAGE and R0[s+1] are issued under it
+        mfma_head(fw1, fa1);
+        KEEP_PIN();
         if (s + NSTAGE < steps) stage(s + NSTAGE, s % NSTAGE);
         read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
-        mfma_group(fw1, fa1);
-        read_frags((s + 1) % NSTAGE, 1, fw1, fa1);
+        KEEP_PIN();
+        mfma_tail(fw1, fa1);
     }
     // drain: fewer tiles in flight, wait for everything that is left
     for (; s < steps - 1; ++s) {
-        mfma_group(fw0, fa0);
+        mfma_head(fw0, fa0);
+        KEEP_PIN();
+        read_frags(s % NSTAGE, 1, fw1, fa1);
+        KEEP_PIN();
+        mfma_tail(fw0, fa0);
+        KEEP_PIN();
         wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        KEEP_PIN();
+        mfma_head(fw1, fa1);
+        KEEP_PIN();
         read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
-        mfma_group(fw1, fa1);
-        read_frags((s + 1) % NSTAGE, 1, fw1, fa1);
+        KEEP_PIN();
+        mfma_tail(fw1, fa1);
     }
-    mfma_group(fw0, fa0);
+    mfma_head(fw0, fa0);
+    KEEP_PIN();
+    read_frags(s % NSTAGE, 1, fw1, fa1);
+    KEEP_PIN();
+    mfma_tail(fw0, fa0);
     mfma_group(fw1, fa1);
+#undef KEEP_PIN
 
     if (p.dbg) t_loop = __builtin_readcyclecounter();
 
