@@ -83,6 +83,9 @@ int keep_bert_layers(keep_handle* h);
  *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
  *   "max_tiles"       tiles per internal sub-batch of keep_encode_image (default 256)
  *   "max_prompts"     prompts per internal sub-batch of keep_encode_text (default 64)
+ *   "streams"         concurrent sub-batches inside keep_encode_image (default 2, 1..4): the batch is split
+ *                     into that many lanes on internal HIP streams, issued layer-interleaved, and joined
+ *                     back onto the caller's stream with events (no host synchronisation)
  *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256: 256xBN LDS-DMA variant
  *                     (process-wide kernel selection override, for tests and A/B measurements)
  */

@@ -73,6 +73,9 @@ struct keep_handle {
     int strict_blocks = 0;
     int max_tiles = 256;
     int max_prompts = 64;
+    int n_streams = 2;           // concurrent sub-batches inside keep_encode_image (1 = everything on the caller's stream)
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 
     // workspace arena
     char* arena = nullptr;
@@ -231,10 +234,16 @@ GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M
 }
 
 // ---------------------------------------------------------------------------------------------
-int vit_chunk(keep_handle* h, const void* pixels, int pix_dtype, int Bc, float* out, hipStream_t s) {
-    const bool any_split = h->any_split();
-    const int D = h->vit_D, M = Bc * 197;
-    VitWs ws = carve_vit(h, h->arena, Bc, any_split);
+// One sub-batch of tiles in flight on one stream ("lane").  keep_encode_image runs up to n_streams lanes
+// concurrently and issues their kernels layer-interleaved, so one lane's memory-bound phases (LayerNorm,
+// attention staging, GEMM epilogues, partial last rounds of workgroups) overlap the other lane's MFMA phases.
+struct VitLane {
+    const void* pixels; int pix_dtype; int Bc; float* out; hipStream_t s; VitWs ws;
+};
+
+int vit_begin(keep_handle* h, VitLane& L) {
+    const int D = h->vit_D, Bc = L.Bc;
+    hipStream_t s = L.s; VitWs& ws = L.ws; const void* pixels = L.pixels; const int pix_dtype = L.pix_dtype;
     // The patch embed is 0.25 % of the FLOPs but its rounding error feeds all 24 blocks: always run it
     // as the hi/lo split product.
     const bool sp0 = true;
@@ -251,7 +260,13 @@ int vit_chunk(keep_handle* h, const void* pixels, int pix_dtype, int Bc, float* 
         p.resid = ws.resid;
         launch_gemm_f16(p, EPI_PATCH, s);
     }
-    for (int i = 0; i < h->vit_depth; ++i) {
+    return KEEP_OK;
+}
+
+int vit_layer(keep_handle* h, VitLane& L, int i) {
+    const int D = h->vit_D, Bc = L.Bc, M = Bc * 197;
+    hipStream_t s = L.s; VitWs& ws = L.ws;
+    {
         const VitBlock& b = h->vblocks[i];
         const bool sp = h->split_layer(i);
         LnParams ln{};
@@ -299,6 +314,12 @@ int vit_chunk(keep_handle* h, const void* pixels, int pix_dtype, int Bc, float* 
             launch_gemm_f16(p, EPI_RESID_LS, s);
         }
     }
+    return KEEP_OK;
+}
+
+int vit_end(keep_handle* h, VitLane& L) {
+    const int D = h->vit_D, Bc = L.Bc;
+    hipStream_t s = L.s; VitWs& ws = L.ws; float* out = L.out;
     {
         // final LayerNorm is per-token, global_pool='token' reads row 0 only -> normalise CLS rows only
         Scope sc(h, T_VIT_HEAD, s);
@@ -627,6 +648,8 @@ int keep_destroy(keep_handle* h) {
     for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
     if (h->arena) hipFree(h->arena);
     if (h->err_flag) hipFree(h->err_flag);
+    for (int l = 0; l < 4; ++l) { if (h->aux[l]) hipStreamDestroy(h->aux[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
     delete h;
     return KEEP_OK;
 }
@@ -676,6 +699,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
+    else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
     else if (n == "gemm_ablate") { g_gemm_ablate = v; }
     else if (n == "gemm_stagger_pct") { g_gemm_stagger_pct = v; }
     else if (n == "gemm_dbg") {
@@ -694,6 +718,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "max_tiles") return h->max_tiles;
     if (n == "max_prompts") return h->max_prompts;
     if (n == "gemm_impl") return g_gemm_impl;
+    if (n == "streams") return h->n_streams;
     return -1;
 }
 
@@ -702,8 +727,11 @@ int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
     HIPCHK(h, hipSetDevice(h->device));
     size_t need = 0;
     if (tiles > 0 && h->vit_depth) {
-        const int64_t bc = tiles < h->max_tiles ? tiles : h->max_tiles;
-        need = vit_ws_bytes(h, bc, h->any_split());
+        int lanes = h->n_streams;
+        while (lanes > 1 && tiles < (int64_t)lanes * 32) --lanes;
+        int64_t per = (tiles + lanes - 1) / lanes;
+        if (per > h->max_tiles) per = h->max_tiles;
+        need = align_up(vit_ws_bytes(h, per, h->any_split())) * lanes;
     }
     if (prompts > 0 && seq > 0 && h->bert_layers) {
         const int64_t pc = prompts < h->max_prompts ? prompts : h->max_prompts;
@@ -722,15 +750,49 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     if (B == 0) return KEEP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    const int64_t bc_max = B < h->max_tiles ? B : h->max_tiles;
-    int rc = ensure_arena(h, vit_ws_bytes(h, bc_max, h->any_split()));
+    // lanes: split the batch over n_streams concurrent sub-batches once there is enough work for each
+    int lanes = h->n_streams;
+    while (lanes > 1 && B < (int64_t)lanes * 32) --lanes;
+    int64_t per = (B + lanes - 1) / lanes;
+    if (per > h->max_tiles) per = h->max_tiles;
+    const bool split = h->any_split();
+    const size_t lane_bytes = align_up(vit_ws_bytes(h, per, split));
+    int rc = ensure_arena(h, lane_bytes * lanes);
     if (rc) return rc;
-    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : 2;
-    for (int64_t b0 = 0; b0 < B; b0 += bc_max) {
-        const int bc = (int)((B - b0) < bc_max ? (B - b0) : bc_max);
-        rc = vit_chunk(h, (const char*)pixels + (size_t)b0 * 3 * 224 * 224 * px, pix_dtype, bc, out + b0 * h->proj_dim, s);
-        if (rc) return rc;
+    if (lanes > 1) {
+        if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int l = 0; l < lanes; ++l) {
+            if (!h->aux[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->aux[l], hipStreamNonBlocking));
+            if (!h->ev_join[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventRecord(h->ev_fork, s));
+        for (int l = 0; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->aux[l], h->ev_fork, 0));
     }
+    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : 2;
+    for (int64_t b0 = 0; b0 < B; b0 += per * lanes) {
+        VitLane L[4];
+        int nl = 0;
+        for (int l = 0; l < lanes; ++l) {
+            const int64_t lo = b0 + l * per;
+            if (lo >= B) break;
+            VitLane& x = L[nl++];
+            x.Bc = (int)((B - lo) < per ? (B - lo) : per);
+            x.pixels = (const char*)pixels + (size_t)lo * 3 * 224 * 224 * px;
+            x.pix_dtype = pix_dtype;
+            x.out = out + lo * h->proj_dim;
+            x.s = lanes > 1 ? h->aux[l] : s;
+            x.ws = carve_vit(h, h->arena + (size_t)l * lane_bytes, x.Bc, split);
+        }
+        for (int l = 0; l < nl; ++l) if ((rc = vit_begin(h, L[l]))) return rc;
+        for (int i = 0; i < h->vit_depth; ++i)
+            for (int l = 0; l < nl; ++l) if ((rc = vit_layer(h, L[l], i))) return rc;
+        for (int l = 0; l < nl; ++l) if ((rc = vit_end(h, L[l]))) return rc;
+    }
+    if (lanes > 1)
+        for (int l = 0; l < lanes; ++l) {
+            HIPCHK(h, hipEventRecord(h->ev_join[l], h->aux[l]));
+            HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[l], 0));
+        }
     return KEEP_OK;
 }
 
