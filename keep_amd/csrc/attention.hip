@@ -247,14 +247,16 @@ void attention_kernel(AttnParams p) {
         }
 #undef KEEP_MEM_BARRIER
         if (q < ntok) {
-            const int64_t orow = (tok0 + q) * D + h * HD;
+            const int mrow = (int)(tok0 + q);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f16x4 oh, ol;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f16 hh, ll; split_f16(o[dt][r] * inv, hh, ll); oh[r] = hh; ol[r] = ll; }
-                *reinterpret_cast<f16x4*>(p.out_hi + orow + dt * 16 + g * 4) = oh;
-                if (SPLIT) *reinterpret_cast<f16x4*>(p.out_lo + orow + dt * 16 + g * 4) = ol;
+                const int col = h * HD + dt * 16 + g * 4;
+                const int64_t oo = p.out_kt > 0 ? blk_off(mrow, col, p.out_kt) : (int64_t)mrow * D + col;
+                *reinterpret_cast<f16x4*>(p.out_hi + oo) = oh;
+                if (SPLIT) *reinterpret_cast<f16x4*>(p.out_lo + oo) = ol;
             }
         }
     }

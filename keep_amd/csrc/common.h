@@ -43,6 +43,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------
+// K-blocked fp16 operand layout ("blk").  Every fp16 matrix that a GEMM reads as an operand (LN output,
+// attention output, MLP hidden, im2col patches, all weights) is stored as
+//     X[m][k]  ->  ((m / 256) * KT + k / 32) * 8192 + (m % 256) * 32 + (k % 32),     KT = K / 32
+// i.e. tile-major [row tile of 256][K slice of 32][256 rows][32 k]: the 16 KiB that one workgroup needs
+// for one K step of one operand is ONE contiguous block.  Measured with tools/ubench/glds_tile_bw.hip:
+// the LDS-DMA stream of the 256x256 GEMM runs at 21.5 TB/s on this layout against 13.7 TB/s on
+// row-major [M][K] (64-byte pieces at a 2 KiB pitch), which was what bounded the K loop.
+// Rows are padded to a multiple of 256 (padding rows are never stored by a consumer).
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int64_t blk_off(int m, int k, int KT) {
+    return ((int64_t)(m >> 8) * KT + (k >> 5)) * 8192 + ((m & 255) << 5) + (k & 31);
+}
+static inline size_t blk_elems(int64_t M, int64_t K) { return (size_t)((M + 255) / 256 * 256) * (size_t)K; }
+
+// ---------------------------------------------------------------------------
 // Kernel launch parameter blocks (plain structs, passed by value)
 // ---------------------------------------------------------------------------
 
@@ -56,8 +71,8 @@ enum GemmEpi : int {
 };
 
 struct GemmParams {
-    const f16* a_hi; const f16* a_lo;     // [M][K] activations (lo plane only when nseg==3)
-    const f16* w_hi; const f16* w_lo;     // [N][K] weights
+    const f16* a_hi; const f16* a_lo;     // activations [M][K] in blk layout (row-major for the v1 kernel); lo only when nseg==3
+    const f16* w_hi; const f16* w_lo;     // weights [N][K], same layout as A
     int M, N, K;                          // K = per-segment depth; multiples: N%128==0, K%64==0
     int nseg;                             // 1: A_hi*W_hi ; 3: A_hi*W_hi + A_lo*W_hi + A_hi*W_lo
     const float* bias;                    // [N]
@@ -66,18 +81,21 @@ struct GemmParams {
     float* resid;                         // fp32 [M'][N]
     float* out_f32;                       // EPI_RESID_F32
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
+    int out_kt;                           // > 0: fp16 output in blk layout with KT = out_kt (= N/32); 0: row-major [M][N]
     int patches_per_img;                  // EPI_PATCH: 196
     int stagger_cycles;                   // first-round workgroup b sleeps b/256 * stagger_cycles (phase-spreads the epilogues)
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
     int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
 };
 
-void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);
+void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);            // blk-layout operands (product path)
+void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s);   // row-major operands (test cross-check)
 
 // Attention over a fused [M][3*D] qkv buffer (token-major; q|k|v, head-major inside each).
 struct AttnParams {
     const f16* qkv_hi; const f16* qkv_lo; // lo only in split mode
-    f16* out_hi; f16* out_lo;             // [M][D]
+    f16* out_hi; f16* out_lo;             // [M][D] row-major, or blk layout when out_kt > 0
+    int out_kt;
     const int64_t* mask;                  // [batch][ntok] (1 = attend) or nullptr
     int batch, ntok, heads;               // head_dim fixed at 64
     int split;                            // 0/1
@@ -91,7 +109,8 @@ struct LnParams {
     const float* add;                     // optional second addend (same stride as x)   [unused when null]
     const float* gamma; const float* beta;
     int rows, D; float eps;
-    f16* out_hi; f16* out_lo;             // [rows][D] dense (nullable)
+    f16* out_hi; f16* out_lo;             // [rows][D] dense (nullable); blk layout when out_kt > 0
+    int out_kt;
     float* out_f32; int64_t out_f32_stride;   // nullable
 };
 int launch_layernorm(const LnParams& p, hipStream_t s);
@@ -109,9 +128,13 @@ struct SgemmParams {
 int launch_sgemm_f32(const SgemmParams& p, hipStream_t s);
 
 // Row-wise helpers (rowops.hip)
-void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_lo,
+void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_lo,      // out in blk layout (KT = 24)
                    const float* cls, const float* pos, float* resid, int D, hipStream_t s);
 void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s);
+// row-major fp32 [M][K] -> blk-layout fp16 hi (+lo); rows M..pad are zero-filled
+void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hipStream_t s);
+// blk-layout fp16 hi (+lo) -> row-major fp32 [M][K]
+void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s);
 void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s);
 void launch_row_argmax(const float* x, int rows, int cols, int32_t* out, hipStream_t s);
 void launch_row_softmax(const float* x, int rows, int cols, float scale, float* out, hipStream_t s);
@@ -120,7 +143,7 @@ void launch_top2_score(const float* x, int rows, int cols, float* partial, float
 void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const float* wemb, const float* pemb,
                           const float* temb, const float* gamma, const float* beta, float eps,
                           int P, int T, int D, int vocab, int type_vocab,
-                          float* resid, f16* out_hi, f16* out_lo, int* err_flag, hipStream_t s);
+                          float* resid, f16* out_hi, f16* out_lo /* blk layout */, int* err_flag, hipStream_t s);
 void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s);
 
 enum PixelDType : int { PIX_F32 = 0, PIX_F16 = 1, PIX_BF16 = 2 };

@@ -176,34 +176,34 @@ struct TxtWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att
 
 size_t vit_ws_bytes(const keep_handle* h, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F, k = split ? 2 : 1;
-    return align_up(M * D * 4) + k * (align_up(M * D * 2) * 2 + align_up(M * 3 * D * 2) + align_up(M * F * 2)) + 2 * align_up(Mp * 768 * 2) +
+    return align_up(M * D * 4) + k * (align_up(blk_elems(M, D) * 2) * 2 + align_up(M * 3 * D * 2) + align_up(blk_elems(M, F) * 2)) + 2 * align_up(blk_elems(Mp, 768) * 2) +
            align_up((size_t)Bc * D * 4) + align_up((size_t)Bc * h->proj_dim * 4) + 4096;
 }
 VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F;
     Carver c(arena); VitWs w{};
     w.resid = c.take<float>(M * D);
-    w.xn_hi = c.take<f16>(M * D);      w.xn_lo = split ? c.take<f16>(M * D) : nullptr;
-    w.qkv_hi = c.take<f16>(M * 3 * D); w.qkv_lo = split ? c.take<f16>(M * 3 * D) : nullptr;
-    w.att_hi = c.take<f16>(M * D);     w.att_lo = split ? c.take<f16>(M * D) : nullptr;
-    w.mlp_hi = c.take<f16>(M * F);     w.mlp_lo = split ? c.take<f16>(M * F) : nullptr;
-    w.pat_hi = c.take<f16>(Mp * 768);  w.pat_lo = c.take<f16>(Mp * 768);
+    w.xn_hi = c.take<f16>(blk_elems(M, D));  w.xn_lo = split ? c.take<f16>(blk_elems(M, D)) : nullptr;
+    w.qkv_hi = c.take<f16>(M * 3 * D);       w.qkv_lo = split ? c.take<f16>(M * 3 * D) : nullptr;
+    w.att_hi = c.take<f16>(blk_elems(M, D)); w.att_lo = split ? c.take<f16>(blk_elems(M, D)) : nullptr;
+    w.mlp_hi = c.take<f16>(blk_elems(M, F)); w.mlp_lo = split ? c.take<f16>(blk_elems(M, F)) : nullptr;
+    w.pat_hi = c.take<f16>(blk_elems(Mp, 768)); w.pat_lo = c.take<f16>(blk_elems(Mp, 768));
     w.cls = c.take<float>((size_t)Bc * D);
     w.h1 = c.take<float>((size_t)Bc * h->proj_dim);
     return w;
 }
 size_t txt_ws_bytes(const keep_handle* h, int64_t Pc, int64_t T, bool split) {
     const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F, k = split ? 2 : 1;
-    return align_up(M * H * 4) + k * (align_up(M * H * 2) * 2 + align_up(M * 3 * H * 2) + align_up(M * F * 2)) + 4096;
+    return align_up(M * H * 4) + k * (align_up(blk_elems(M, H) * 2) * 2 + align_up(M * 3 * H * 2) + align_up(blk_elems(M, F) * 2)) + 4096;
 }
 TxtWs carve_txt(const keep_handle* h, char* arena, int64_t Pc, int64_t T, bool split) {
     const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F;
     Carver c(arena); TxtWs w{};
     w.resid = c.take<float>(M * H);
-    w.xn_hi = c.take<f16>(M * H);      w.xn_lo = split ? c.take<f16>(M * H) : nullptr;
-    w.qkv_hi = c.take<f16>(M * 3 * H); w.qkv_lo = split ? c.take<f16>(M * 3 * H) : nullptr;
-    w.att_hi = c.take<f16>(M * H);     w.att_lo = split ? c.take<f16>(M * H) : nullptr;
-    w.mlp_hi = c.take<f16>(M * F);     w.mlp_lo = split ? c.take<f16>(M * F) : nullptr;
+    w.xn_hi = c.take<f16>(blk_elems(M, H));  w.xn_lo = split ? c.take<f16>(blk_elems(M, H)) : nullptr;
+    w.qkv_hi = c.take<f16>(M * 3 * H);       w.qkv_lo = split ? c.take<f16>(M * 3 * H) : nullptr;
+    w.att_hi = c.take<f16>(blk_elems(M, H)); w.att_lo = split ? c.take<f16>(blk_elems(M, H)) : nullptr;
+    w.mlp_hi = c.take<f16>(blk_elems(M, F)); w.mlp_lo = split ? c.take<f16>(blk_elems(M, F)) : nullptr;
     return w;
 }
 
@@ -271,7 +271,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         const bool sp = h->split_layer(i);
         LnParams ln{};
         ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
-        ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr;
+        ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr; ln.out_kt = D / 32;
         {
             Scope sc(h, T_VIT_LN, s);
             ln.gamma = b.n1w; ln.beta = b.n1b;
@@ -287,7 +287,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_ATTN, s);
             AttnParams a{};
             a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
-            a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f;
+            a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
             if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
         }
         {
@@ -304,7 +304,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         {
             Scope sc(h, T_VIT_FC1, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.fc1, M, sp, b.fc1_b);
-            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr;
+            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
             launch_gemm_f16(p, EPI_GELU_F16, s);
         }
         {
@@ -370,7 +370,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_ATTN, s);
             AttnParams a{};
             a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
-            a.mask = mask; a.batch = Pc; a.ntok = T; a.heads = h->bert_heads; a.split = sp; a.scale = 0.125f;
+            a.mask = mask; a.batch = Pc; a.ntok = T; a.heads = h->bert_heads; a.split = sp; a.scale = 0.125f; a.out_kt = H / 32;
             if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %d unsupported%s", T,
                                                        sp ? " in strict mode (max 256)" : " (max 512)");
         }
@@ -382,7 +382,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
         }
         LnParams ln{};
         ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
-        ln.out_f32 = ws.resid; ln.out_f32_stride = H; ln.out_hi = ws.xn_hi;
+        ln.out_f32 = ws.resid; ln.out_f32_stride = H; ln.out_hi = ws.xn_hi; ln.out_kt = H / 32;
         {
             Scope sc(h, T_TXT_LN, s);
             ln.gamma = b.ln1w; ln.beta = b.ln1b; ln.out_lo = sp ? ws.xn_lo : nullptr;
@@ -391,7 +391,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
         {
             Scope sc(h, T_TXT_FFN1, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
-            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr;
+            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->bert_F / 32;
             launch_gemm_f16(p, EPI_GELU_F16, s);
         }
         {
@@ -423,9 +423,12 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
     WTensor t; t.shape = shape; t.numel = numel_of(shape);
     if (t.numel <= 0) return h->fail(KEEP_EINVAL, "%s: empty tensor", key.c_str());
     if (is_gemm_weight(key)) {
+        // fp16 hi/lo planes in blk layout; rows (out features) must fill whole 256-row tiles
+        const int64_t n = t.shape[0], k = t.numel / t.shape[0];
+        if (n % 256 || k % 32) return h->fail(KEEP_EUNSUPPORTED, "%s: [%lld,%lld] is not tileable (rows %% 256, cols %% 32)", key.c_str(), (long long)n, (long long)k);
         HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
         HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
-        launch_split_f16(dev, t.hi, t.lo, t.numel, nullptr);
+        launch_split_blockify(dev, t.hi, t.lo, (int)n, (int)k, nullptr);
         HIPCHK(h, hipStreamSynchronize(nullptr));
     } else {
         const size_t bytes = (size_t)(t.numel > 4 ? t.numel : 4) * sizeof(float);
@@ -498,7 +501,7 @@ int finalize_vit(keep_handle* h) {
         h->vblocks.push_back(b);
     }
     if (!miss.empty()) return h->fail(KEEP_EKEY, "missing or mis-shaped key(s): %s", miss.c_str());
-    if (F % 128 || D % 128 || PJ % 16) return h->fail(KEEP_EUNSUPPORTED, "ViT dims not tileable");
+    if (F % 256 || D % 256 || PJ % 16) return h->fail(KEEP_EUNSUPPORTED, "ViT dims not tileable");
     h->vit_depth = depth; h->vit_D = (int)D; h->vit_heads = (int)(D / 64); h->vit_F = (int)F; h->proj_dim = (int)PJ;
     return KEEP_OK;
 }
@@ -564,7 +567,7 @@ int finalize_bert(keep_handle* h) {
         }
     }
     if (!miss.empty()) { h->blayers.clear(); return h->fail(KEEP_EKEY, "missing or mis-shaped key(s): %s", miss.c_str()); }
-    if (F % 128 || H % 128) return h->fail(KEEP_EUNSUPPORTED, "BERT dims not tileable");
+    if (F % 256 || H % 256) return h->fail(KEEP_EUNSUPPORTED, "BERT dims not tileable");
     h->bert_layers = L; h->bert_H = (int)H; h->bert_heads = (int)(H / 64); h->bert_F = (int)F;
     h->bert_vocab = (int)V; h->bert_maxpos = (int)pos->shape[0]; h->bert_types = (int)typ->shape[0];
     return KEEP_OK;
@@ -896,32 +899,38 @@ int keep_profile_reset(keep_handle* h) {
 int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls, const float* resid,
                    int64_t M, int64_t N, int64_t K, int epi, int split, float* out, void* stream) {
     if (!h || !a || !w || !bias || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
-    if (M < 1 || N % 128 || K % 64 || N < 128 || K < 64) return h->fail(KEEP_EUNSUPPORTED, "linear needs N%%128==0, K%%64==0");
+    const bool rowmajor = (g_gemm_impl == 1);      // cross-check variant: 128x128 register-staged kernel on row-major operands
+    if (M < 1 || N % 128 || N < 128 || K < 64 || K % (rowmajor ? 64 : 32)) return h->fail(KEEP_EUNSUPPORTED, "linear needs N%%128==0 and K%%32==0 (K%%64 for gemm_impl=1)");
     if (epi != EPI_F16 && epi != EPI_GELU_F16 && epi != EPI_RESID_LS && epi != EPI_RESID_F32) return h->fail(KEEP_EINVAL, "epilogue %d", epi);
     if ((epi == EPI_RESID_LS && (!ls || !resid)) || (epi == EPI_RESID_F32 && !resid)) return h->fail(KEEP_EINVAL, "missing ls/resid");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     Tmp t;
-    f16* a_hi = t.get<f16>(M * K); f16* a_lo = t.get<f16>(M * K);
-    f16* w_hi = t.get<f16>(N * K); f16* w_lo = t.get<f16>(N * K);
-    f16* o_hi = t.get<f16>(M * N); f16* o_lo = t.get<f16>(M * N);
+    const size_t ae = blk_elems(M, K), we = blk_elems(N, K), oe = blk_elems(M, N);
+    f16* a_hi = t.get<f16>(ae); f16* a_lo = t.get<f16>(ae);
+    f16* w_hi = t.get<f16>(we); f16* w_lo = t.get<f16>(we);
+    f16* o_hi = t.get<f16>(oe); f16* o_lo = t.get<f16>(oe);
     if (!a_hi || !a_lo || !w_hi || !w_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
-    launch_split_f16(a, a_hi, a_lo, M * K, s);
-    launch_split_f16(w, w_hi, w_lo, N * K, s);
+    if (rowmajor) { launch_split_f16(a, a_hi, a_lo, M * K, s); launch_split_f16(w, w_hi, w_lo, N * K, s); }
+    else { launch_split_blockify(a, a_hi, a_lo, (int)M, (int)K, s); launch_split_blockify(w, w_hi, w_lo, (int)N, (int)K, s); }
     GemmParams p{};
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.nseg = split ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
+    auto launch = [&](const GemmParams& q) { if (rowmajor) launch_gemm_f16_rowmajor(q, epi, s); else launch_gemm_f16(q, epi, s); };
     if (epi == EPI_F16 || epi == EPI_GELU_F16) {
         p.out_hi = o_hi; p.out_lo = split ? o_lo : nullptr;
-        launch_gemm_f16(p, epi, s);
-        planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * N, s);
+        // as in the towers: the GELU output feeds another GEMM (blk layout), the plain one feeds attention (row-major)
+        p.out_kt = (!rowmajor && epi == EPI_GELU_F16) ? (int)(N / 32) : 0;
+        launch(p);
+        if (p.out_kt) launch_unblockify_f32(o_hi, split ? o_lo : nullptr, out, (int)M, (int)N, s);
+        else planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * N, s);
     } else if (epi == EPI_RESID_LS) {
         HIPCHK(h, hipMemcpyAsync(out, resid, M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
         p.resid = out;
-        launch_gemm_f16(p, epi, s);
+        launch(p);
     } else {
         p.resid = const_cast<float*>(resid); p.out_f32 = out;
-        launch_gemm_f16(p, epi, s);
+        launch(p);
     }
     HIPCHK(h, hipStreamSynchronize(s));
     return check_launch(h, "op_linear");
@@ -935,14 +944,16 @@ int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int
     const int64_t M = B * T, D = (int64_t)heads * 64;
     Tmp t;
     f16* q_hi = t.get<f16>(M * 3 * D); f16* q_lo = t.get<f16>(M * 3 * D);
-    f16* o_hi = t.get<f16>(M * D); f16* o_lo = t.get<f16>(M * D);
+    // the towers write the attention output in blk layout when the width allows it (D % 32 == 0 always holds)
+    const size_t oe = blk_elems(M, D);
+    f16* o_hi = t.get<f16>(oe); f16* o_lo = t.get<f16>(oe);
     if (!q_hi || !q_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
     launch_split_f16(qkv, q_hi, q_lo, M * 3 * D, s);
     AttnParams a{};
     a.qkv_hi = q_hi; a.qkv_lo = q_lo; a.out_hi = o_hi; a.out_lo = split ? o_lo : nullptr; a.mask = mask;
-    a.batch = (int)B; a.ntok = (int)T; a.heads = heads; a.split = split; a.scale = 0.125f;
+    a.batch = (int)B; a.ntok = (int)T; a.heads = heads; a.split = split; a.scale = 0.125f; a.out_kt = (int)(D / 32);
     if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
-    planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * D, s);
+    launch_unblockify_f32(o_hi, split ? o_lo : nullptr, out, (int)M, (int)D, s);
     HIPCHK(h, hipStreamSynchronize(s));
     return check_launch(h, "op_attention");
 }

@@ -149,18 +149,19 @@ int g_gemm_stagger_pct = 0;   // stagger span as % of the estimated tile time (0
 int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
 
 void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
+    // Operands in blk layout -> the LDS-DMA kernels (gemm_f16_v2.hip); g_gemm_impl only picks the tile width.
     GemmParams p = p_in;
     p.ablate = g_gemm_ablate;
     p.dbg = g_gemm_dbg;
     // estimated 256x256 tile time: ~2000 cycles per 32-deep K step + ~10k cycles of prologue/epilogue
     p.stagger_cycles = (int)((2000LL * (p.K / 32) * p.nseg + 10000) * g_gemm_stagger_pct / 100);
     int impl = g_gemm_impl;
-    if (impl == 0) {
-        if (p.N % 256 == 0 && p.M >= 1024) impl = 256;
-        else if (p.N % 128 == 0 && p.M >= 512) impl = 128;
-        else impl = 1;
-    }
-    if (impl != 1 && launch_gemm_f16_v2(p, epi, impl, s) == 0) return;
+    if ((impl != 128 && impl != 256) || (impl == 256 && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
+    launch_gemm_f16_v2(p, epi, impl, s);
+}
+
+// Row-major operands: the register-staged 128x128 kernel above (cross-check variant for the op tests).
+void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid(p.N / BN, (p.M + BM - 1) / BM), block(THREADS);
     switch (epi) {
         case EPI_F16:       hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_F16>, grid, block, 0, s, p); break;

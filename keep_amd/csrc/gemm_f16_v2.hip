@@ -5,10 +5,11 @@
 // Structure (MI355X guide: "glds, 2 LDS buffers, BK=64, one barrier per K tile"):
 //   * workgroup = 512 threads = 8 waves, WM x WN; each wave owns (256/WM) x (BN/WN) outputs as
 //     32x32x16 MFMA tiles (operand swap as in v1: lanes hold 4 consecutive n of one m)
-//   * both operands are staged with global_load_lds_dwordx4 (16 B per lane straight into LDS, no
-//     VGPR round trip).  The DMA writes LDS linearly (wave base + lane*16), so the XOR swizzle that
-//     makes ds_read_b128 conflict-free is applied to the per-lane GLOBAL source address instead:
-//     LDS slot (row, s) holds logical 16-B chunk s ^ ((row>>1)&7) of that row
+//   * both operands live in HBM in the K-blocked "blk" layout (common.h) and are staged with
+//     global_load_lds_dwordx4 (16 B per lane straight into LDS, no VGPR round trip).  The DMA writes LDS
+//     linearly (wave base + lane*16), so the XOR swizzle that makes ds_read_b128 conflict-free is
+//     applied to the per-lane GLOBAL source address instead: LDS slot (row, s) holds logical 16-B
+//     chunk s ^ ((row>>2)&3) of that 64-byte row
 //   * a ring of NSTAGE LDS buffers of BK = 32 (256 + BN rows x 64 B each).  One K tile in flight is
 //     latency-bound (a 64 KiB DMA burst takes ~1.9 us to land, measured: that alone set the step
 //     time), so NSTAGE-1 tiles are kept in flight: the wait before using tile s is a COUNTED
@@ -81,30 +82,34 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int n0 = tn * BN;
 
     const int swz_mask = (p.ablate & 4) ? 0 : 3;     // diagnostics: ablate&4 disables the swizzle on both sides
-    // ---- DMA source offsets (elements) per round; LDS slot L = round*512 + tid -> row L>>3, slot L&7
-    int64_t a_off[A_ROUNDS], w_off[B_ROUNDS];
+    // ---- DMA source offsets.  Operands are in blk layout (common.h): the 256 x 32 slice of one operand
+    // for one K step is 16 KiB contiguous, so LDS slot L = round*512 + tid (row L/4, slot L%4) reads
+    // byte (L/4)*64 + ((L%4) ^ swz)*16 of the slice: every DMA instruction covers 1 KiB of contiguous HBM.
+    const int KT = p.K / BK;
+    int a_off[A_ROUNDS], w_off[B_ROUNDS];
 #pragma unroll
     for (int r = 0; r < A_ROUNDS; ++r) {
         const int L = r * V2_THREADS + tid;
         const int row = L / SLOTS, c = (L % SLOTS) ^ v2_swz(row, swz_mask);
-        int am = m0 + row; am = am < p.M ? am : p.M - 1;
-        a_off[r] = (int64_t)am * p.K + c * 8;
+        a_off[r] = row * BK + c * 8;
     }
 #pragma unroll
     for (int r = 0; r < B_ROUNDS; ++r) {
         const int L = r * V2_THREADS + tid;
         const int row = L / SLOTS, c = (L % SLOTS) ^ v2_swz(row, swz_mask);
-        w_off[r] = (int64_t)(n0 + row) * p.K + c * 8;
+        w_off[r] = ((n0 & 255) + row) * BK + c * 8;
     }
+    const int64_t a_tile = (int64_t)(m0 >> 8) * KT * 8192;
+    const int64_t w_tile = (int64_t)(n0 >> 8) * KT * 8192;
 
-    const int ktiles = p.K / BK;
+    const int ktiles = KT;
     const int steps = ktiles * p.nseg;
 
     auto stage = [&](int s, int buf) {
         const int seg = s / ktiles;
-        const int kk = (s - seg * ktiles) * BK;
-        const f16* ab = ((seg == 1) ? p.a_lo : p.a_hi) + kk;
-        const f16* wb = ((seg == 2) ? p.w_lo : p.w_hi) + kk;
+        const int kt = s - seg * ktiles;
+        const f16* ab = ((seg == 1) ? p.a_lo : p.a_hi) + a_tile + (int64_t)kt * 8192;
+        const f16* wb = ((seg == 2) ? p.w_lo : p.w_hi) + w_tile + (int64_t)kt * 8192;
         f16* sa = lds + buf * BUF_ELEMS;
         f16* sw = sa + BM * BK;
 #pragma unroll
@@ -282,7 +287,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     split_f16(b, hh, ll); h[4 + e] = hh; l[4 + e] = ll;
                 }
                 if (m < p.M) {
-                    const int64_t o = (int64_t)m * p.N + ncol;
+                    const int64_t o = p.out_kt > 0 ? blk_off(m, ncol, p.out_kt) : (int64_t)m * p.N + ncol;
                     *reinterpret_cast<f16x8*>(p.out_hi + o) = h;
                     if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = l;
                 }

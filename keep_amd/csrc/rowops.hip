@@ -54,8 +54,9 @@ void layernorm_kernel(LnParams p) {
             f16 hh, ll; split_f16(y[e], hh, ll); h[e] = hh; l[e] = ll;
         }
         if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (int64_t)row * p.out_f32_stride + col) = y;
-        if (p.out_hi) *reinterpret_cast<f16x4*>(p.out_hi + (int64_t)row * (NV * 256) + col) = h;
-        if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + (int64_t)row * (NV * 256) + col) = l;
+        const int64_t o16 = p.out_kt > 0 ? blk_off(row, col, p.out_kt) : (int64_t)row * (NV * 256) + col;
+        if (p.out_hi) *reinterpret_cast<f16x4*>(p.out_hi + o16) = h;
+        if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + o16) = l;
     }
 }
 
@@ -94,7 +95,7 @@ void im2col_kernel(const void* __restrict__ pixels, int B, f16* __restrict__ out
             }
         }
         const int py = y >> 4, ph = y & 15, px = xc >> 1, half = xc & 1;
-        const int64_t dst = ((int64_t)b * 196 + py * 14 + px) * 768 + c * 256 + ph * 16 + half * 8;
+        const int64_t dst = blk_off(b * 196 + py * 14 + px, c * 256 + ph * 16 + half * 8, 24);
         f16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { f16 hh, ll; split_f16(v[e], hh, ll); h[e] = hh; l[e] = ll; }
@@ -117,6 +118,33 @@ __global__ void split_f16_kernel(const float* __restrict__ src, f16* __restrict_
         f16 h, l; split_f16(src[i], h, l);
         hi[i] = h;
         if (lo) lo[i] = l;
+    }
+}
+
+// ------------------------------------------------------------------ blk-layout conversions (weight prep, op tests)
+__global__ void split_blockify_kernel(const float* __restrict__ src, f16* __restrict__ hi, f16* __restrict__ lo, int M, int K) {
+    const int Mp = (M + 255) / 256 * 256, KT = K / 32;
+    const int64_t total = (int64_t)Mp * (K / 8);           // one work item = 8 consecutive k of one row
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(it / (K / 8)), k = (int)(it % (K / 8)) * 8;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = m < M ? src[(int64_t)m * K + k + e] : 0.f;
+            f16 hh, ll; split_f16(x, hh, ll); h[e] = hh; l[e] = ll;
+        }
+        const int64_t o = blk_off(m, k, KT);
+        *reinterpret_cast<f16x8*>(hi + o) = h;
+        if (lo) *reinterpret_cast<f16x8*>(lo + o) = l;
+    }
+}
+__global__ void unblockify_f32_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo, float* __restrict__ out, int M, int K) {
+    const int KT = K / 32;
+    const int64_t total = (int64_t)M * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / K), k = (int)(i % K);
+        const int64_t o = blk_off(m, k, KT);
+        out[i] = (float)hi[o] + (lo ? (float)lo[o] : 0.f);
     }
 }
 
@@ -255,8 +283,9 @@ void bert_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __rest
             f16 hh, ll; split_f16(y[e], hh, ll); h[e] = hh; l[e] = ll;
         }
         *reinterpret_cast<f32x4*>(resid + (int64_t)row * D + col) = y;
-        *reinterpret_cast<f16x4*>(out_hi + (int64_t)row * D + col) = h;
-        if (out_lo) *reinterpret_cast<f16x4*>(out_lo + (int64_t)row * D + col) = l;
+        const int64_t o16 = blk_off(row, col, D / 32);
+        *reinterpret_cast<f16x4*>(out_hi + o16) = h;
+        if (out_lo) *reinterpret_cast<f16x4*>(out_lo + o16) = l;
     }
 }
 
@@ -297,6 +326,17 @@ void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(split_f16_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, n);
+}
+
+void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hipStream_t s) {
+    const int64_t total = (int64_t)((M + 255) / 256 * 256) * (K / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(split_blockify_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, M, K);
+}
+void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s) {
+    const int64_t total = (int64_t)M * K;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(unblockify_f32_kernel, dim3(blocks), dim3(256), 0, s, hi, lo, out, M, K);
 }
 
 void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s) {
