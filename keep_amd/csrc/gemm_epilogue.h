@@ -31,6 +31,22 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * (x < 0.f ? u : 1.0f - u);
 }
 
+// Two elements at once on the packed fp32 pipe (v_pk_fma_f32): halves the polynomial's issue slots.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 a = __builtin_elementwise_min(__builtin_elementwise_abs(x), (f32x2){6.0f, 6.0f});
+    f32x2 p = {-3.594286202e-09f, -3.594286202e-09f};
+    constexpr float c[11] = {1.257803746e-07f, -1.958191660e-06f, 1.778304431e-05f, -1.016299357e-04f, 3.363231954e-04f,
+                             -7.651424676e-05f, -6.888056640e-03f, 5.241813138e-02f, 4.592245221e-01f, 1.151104093e+00f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 11; ++i) p = __builtin_elementwise_fma(p, a, (f32x2){c[i], c[i]});
+    const float u0 = __builtin_amdgcn_exp2f(-p[0]), u1 = __builtin_amdgcn_exp2f(-p[1]);
+    f32x2 r;
+    r[0] = x[0] * (x[0] < 0.f ? u0 : 1.0f - u0);
+    r[1] = x[1] * (x[1] < 0.f ? u1 : 1.0f - u1);
+    return r;
+}
+
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, int& prow, int64_t& orow) {
     orow = m; prow = 0;

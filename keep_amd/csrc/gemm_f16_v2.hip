@@ -280,11 +280,11 @@ void gemm_f16_v2_kernel(GemmParams p) {
                 f16x8 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float a = x0[e] + bias4[0][e], b = x1[e] + bias4[CPL / 4 - 1][e];
-                    if (EPI == EPI_GELU_F16) { a = gelu_fast(a); b = gelu_fast(b); }
+                    f32x2 ab = {x0[e] + bias4[0][e], x1[e] + bias4[CPL / 4 - 1][e]};
+                    if (EPI == EPI_GELU_F16) ab = gelu_fast2(ab);
                     f16 hh, ll;
-                    split_f16(a, hh, ll); h[e] = hh; l[e] = ll;
-                    split_f16(b, hh, ll); h[4 + e] = hh; l[4 + e] = ll;
+                    split_f16(ab[0], hh, ll); h[e] = hh; l[e] = ll;
+                    split_f16(ab[1], hh, ll); h[4 + e] = hh; l[4 + e] = ll;
                 }
                 if (m < p.M) {
                     const int64_t o = p.out_kt > 0 ? blk_off(m, ncol, p.out_kt) : (int64_t)m * p.N + ncol;
