@@ -119,6 +119,21 @@ int keep_token_error(keep_handle* h, void* stream);
 int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t N, int64_t P, int64_t D,
                     float scale, int mode, void* out, int32_t* argmax_out, void* stream);
 
+/* ---- slide-level zero-shot steps ---------------------------------
+ * Replaces the loop of `zero_shot_prompt_select` (WSI_evaluation/utils.py:127-130: one GEMM + one
+ * rank_cls_score + one .item() sync per prompt classifier).  feats fp32 [N,D] already L2-normalised
+ * (utils.py:125), bank fp32 [K*C, D] = the K classifiers stacked, classifier k occupying rows k*C..k*C+C-1
+ * (i.e. each [D,C] classifier transposed); scores_out fp32 [K] (device) = rank_cls_score of every k. */
+int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, int64_t N, int64_t K, int64_t C,
+                       int64_t D, float* scores_out, void* stream);
+
+/* Replaces `refine_seg` (subtyping_utils.py:38-65, detection_utils.py:39-74, segment_utils.py:63-89).
+ * probs fp32 [N,C] (softmax(10*cos)), coords int64 [N,2].  out_mean fp32 [N,C]: for the first tile of
+ * every distinct coordinate, the float32 mean of the existing tiles among (x-p,y-p),(x,y-p),(x-p,y),(x,y)
+ * (or its own row when overlap == 0); is_first int32 [N]: 1 for those tiles, 0 for later duplicates. */
+int keep_refine(keep_handle* h, const float* probs, const int64_t* coords, int64_t N, int64_t C, int64_t patch,
+                int overlap, float* out_mean, int32_t* is_first, void* stream);
+
 /* ---- profiling (HIP events on the launch stream) ----------------------------------------------
  * tag names: "vit.im2col" "vit.patch" "vit.ln" "vit.qkv" "vit.attn" "vit.proj" "vit.fc1" "vit.fc2"
  * "vit.head" "text.embed" "text.ln" "text.qkv" "text.attn" "text.out" "text.ffn1" "text.ffn2"

@@ -146,4 +146,10 @@ void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const flo
                           float* resid, f16* out_hi, f16* out_lo /* blk layout */, int* err_flag, hipStream_t s);
 void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s);
 
+// wsi.hip
+void launch_group_top2(const float* logits, int n, int K, int C, float* partial, int max_row_blocks, float* sums, hipStream_t s);
+void launch_scale_vec(const float* in, int n, float f, float* out, hipStream_t s);
+void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
+                   unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s);
+
 enum PixelDType : int { PIX_F32 = 0, PIX_F16 = 1, PIX_BF16 = 2 };

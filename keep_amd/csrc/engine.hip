@@ -868,6 +868,53 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
     return check_launch(h, "similarity");
 }
 
+int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, int64_t N, int64_t K, int64_t C, int64_t D,
+                       float* scores_out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!feats || !bank || !scores_out || N < 1 || K < 1 || C < 2 || D < 16 || D % 16) return h->fail(KEEP_EINVAL, "bad prompt_scores arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scope sc(h, T_SIM, s);
+    const int64_t KC = K * C;
+    int64_t chunk = ((int64_t)256 << 20) / (KC * 4);          // <= 256 MiB of logits alive at a time
+    if (chunk < 256) chunk = 256;
+    if (chunk > N) chunk = N;
+    const int max_rb = 64;
+    const size_t b_logits = align_up((size_t)chunk * KC * 4), b_part = align_up((size_t)max_rb * K * 4), b_sums = align_up((size_t)K * 4);
+    int rc = ensure_arena(h, b_logits + b_part + b_sums);
+    if (rc) return rc;
+    float* logits = (float*)h->arena;
+    float* partial = (float*)(h->arena + b_logits);
+    float* sums = (float*)(h->arena + b_logits + b_part);
+    HIPCHK(h, hipMemsetAsync(sums, 0, (size_t)K * 4, s));
+    for (int64_t r0 = 0; r0 < N; r0 += chunk) {
+        const int64_t n = (N - r0) < chunk ? (N - r0) : chunk;
+        SgemmParams g{};
+        g.a = feats + r0 * D; g.lda = D; g.b = bank; g.ldb = D; g.out = logits; g.ldo = KC; g.bias = nullptr;
+        g.M = (int)n; g.N = (int)KC; g.K = (int)D; g.scale = 1.0f; g.act = ACT_NONE;
+        if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "prompt_scores shape");
+        launch_group_top2(logits, (int)n, (int)K, (int)C, partial, max_rb, sums, s);
+    }
+    launch_scale_vec(sums, (int)K, 1.0f / (float)N, scores_out, s);
+    return check_launch(h, "prompt_scores");
+}
+
+int keep_refine(keep_handle* h, const float* probs, const int64_t* coords, int64_t N, int64_t C, int64_t patch, int overlap,
+                float* out_mean, int32_t* is_first, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!probs || !coords || !out_mean || !is_first || N < 1 || C < 1 || N > (1 << 29)) return h->fail(KEEP_EINVAL, "bad refine arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned size = 1024;
+    while ((int64_t)size < 2 * N) size <<= 1;
+    const size_t b_keys = align_up((size_t)size * 8), b_first = align_up((size_t)size * 4);
+    int rc = ensure_arena(h, b_keys + b_first);
+    if (rc) return rc;
+    launch_refine(probs, (const long long*)coords, (int)N, (int)C, (long long)patch, overlap,
+                  (unsigned long long*)h->arena, (int*)(h->arena + b_keys), size, out_mean, (int*)is_first, s);
+    return check_launch(h, "refine");
+}
+
 int keep_profile_enable(keep_handle* h, const char* tag) {
     if (!h) return KEEP_EINVAL;
     if (!tag) { h->prof_mode = 2; return KEEP_OK; }

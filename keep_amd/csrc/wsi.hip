@@ -1,0 +1,128 @@
+// Slide-level zero-shot kernels: the per-tile reductions the reference does
+// in Python loops with one device->host sync per classifier / per tile.
+//
+//   group_top2_partial   rank_cls_score for EVERY prompt classifier at once
+//                        (WSI_evaluation/utils.py:107-117 inside the loop at :127-130):
+//                        logits [n, K*C] -> per classifier k the sum over tiles of (v1-v2) - |v1+v2-1|
+//   coord_insert / refine_mean
+//                        refine_seg (subtyping_utils.py:38-65, detection_utils.py:39-74,
+//                        segment_utils.py:63-89): first occurrence of a coordinate wins; each tile's
+//                        probabilities are averaged over the existing tiles among
+//                        {(x-p,y-p),(x,y-p),(x-p,y),(x,y)} in that order (float32 sum, then / count,
+//                        exactly numpy's mean over <= 4 rows)
+#include "common.h"
+
+namespace keepk {
+
+// one thread per classifier k; a block walks `rows_per_block` tiles.  Consecutive threads read consecutive
+// C-wide groups of one logits row -> coalesced.  partial[rb][k] is written once (deterministic).
+__global__ __launch_bounds__(256)
+void group_top2_partial_kernel(const float* __restrict__ logits, int n, int K, int C, int rows_per_block,
+                               float* __restrict__ partial) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float* p = logits + (int64_t)r * K * C + (int64_t)k * C;
+        float v1 = -INFINITY, v2 = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float v = p[c];
+            if (v > v1) { v2 = v1; v1 = v; } else if (v > v2) { v2 = v; }
+        }
+        acc += (v1 - v2) - fabsf(v1 + v2 - 1.0f);
+    }
+    partial[(int64_t)blockIdx.y * K + k] = acc;
+}
+__global__ __launch_bounds__(256)
+void group_top2_reduce_kernel(const float* __restrict__ partial, int nrb, int K, float* __restrict__ sums) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = sums[k];
+    for (int b = 0; b < nrb; ++b) s += partial[(int64_t)b * K + k];
+    sums[k] = s;
+}
+
+// ---- coordinate hash: open addressing on packed (x, y), value = smallest tile index with that key
+__device__ __forceinline__ unsigned long long pack_xy(long long x, long long y) {
+    return ((unsigned long long)(unsigned)(int)x << 32) | (unsigned long long)(unsigned)(int)y;
+}
+__device__ __forceinline__ unsigned hash_xy(unsigned long long k, unsigned mask) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (unsigned)k & mask;
+}
+constexpr unsigned long long EMPTY_KEY = 0xffffffffffffffffULL;
+
+__global__ void coord_insert_kernel(const long long* __restrict__ coords, int n, unsigned long long* keys, int* first,
+                                    unsigned mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = pack_xy(coords[2 * i], coords[2 * i + 1]);
+    unsigned s = hash_xy(key, mask);
+    while (true) {
+        const unsigned long long prev = atomicCAS(&keys[s], EMPTY_KEY, key);
+        if (prev == EMPTY_KEY || prev == key) { atomicMin(&first[s], i); return; }
+        s = (s + 1) & mask;
+    }
+}
+__device__ __forceinline__ int coord_lookup(const unsigned long long* keys, const int* first, unsigned mask, long long x, long long y) {
+    const unsigned long long key = pack_xy(x, y);
+    unsigned s = hash_xy(key, mask);
+    while (true) {
+        const unsigned long long k = keys[s];
+        if (k == key) return first[s];
+        if (k == EMPTY_KEY) return -1;
+        s = (s + 1) & mask;
+    }
+}
+// one thread per (tile, class); is_first[i] = 1 when tile i is the first with its coordinate
+__global__ void refine_mean_kernel(const float* __restrict__ probs, const long long* __restrict__ coords, int n, int C,
+                                   long long patch, int overlap, const unsigned long long* keys, const int* first,
+                                   unsigned mask, float* __restrict__ out, int* __restrict__ is_first) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * C) return;
+    const int i = (int)(t / C), c = (int)(t % C);
+    const long long x = coords[2 * i], y = coords[2 * i + 1];
+    const int self = coord_lookup(keys, first, mask, x, y);
+    if (c == 0) is_first[i] = (self == i);
+    if (self != i) { out[t] = probs[t]; return; }
+    if (!overlap) { out[t] = probs[t]; return; }
+    const long long nx[4] = {x - patch, x, x - patch, x}, ny[4] = {y - patch, y - patch, y, y};
+    float sum = 0.f; int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = q == 3 ? i : coord_lookup(keys, first, mask, nx[q], ny[q]);
+        if (j >= 0) { sum = cnt == 0 ? probs[(int64_t)j * C + c] : sum + probs[(int64_t)j * C + c]; ++cnt; }
+    }
+    out[t] = sum / (float)cnt;
+}
+
+__global__ void scale_vec_kernel(const float* __restrict__ in, int n, float f, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * f;
+}
+
+}  // namespace keepk
+using namespace keepk;
+
+void launch_scale_vec(const float* in, int n, float f, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, f, out);
+}
+
+void launch_group_top2(const float* logits, int n, int K, int C, float* partial, int max_row_blocks, float* sums, hipStream_t s) {
+    int rpb = (n + max_row_blocks - 1) / max_row_blocks; if (rpb < 1) rpb = 1;
+    const int nrb = (n + rpb - 1) / rpb;
+    dim3 grid((K + 255) / 256, nrb);
+    hipLaunchKernelGGL(group_top2_partial_kernel, grid, dim3(256), 0, s, logits, n, K, C, rpb, partial);
+    hipLaunchKernelGGL(group_top2_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, partial, nrb, K, sums);
+}
+void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
+                   unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s) {
+    (void)hipMemsetAsync(keys, 0xff, (size_t)table_size * 8, s);
+    (void)hipMemsetAsync(first, 0x7f, (size_t)table_size * 4, s);
+    hipLaunchKernelGGL(coord_insert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, coords, n, keys, first, table_size - 1);
+    const int64_t total = (int64_t)n * C;
+    hipLaunchKernelGGL(refine_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probs, coords, n, C, patch, overlap,
+                       keys, first, table_size - 1, out, is_first);
+}
