@@ -20,7 +20,7 @@
 
 namespace keepk {
 
-constexpr int V2_BM = 256, V2_BK = 32, V2_THREADS = 512, V2_NSTAGE = 4;
+constexpr int V2_BM = 256, V2_BK = 32;
 
 // 64-byte LDS rows (4 slots of 16 B): slot ^= (row>>2)&3 spreads any 16 consecutive rows over all
 // 16 distinct (row&3, slot) bank positions -> conflict-free ds_read_b128
@@ -35,9 +35,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(V2_THREADS, 2)
+// <BN, WM, WN, NSTAGE>: 256x256 tile / 8 waves / 4-stage ring = one workgroup per CU (128 KiB LDS);
+//                        256x128 tile / 4 waves / 3-stage ring = TWO workgroups per CU (72 KiB LDS each): one
+//                        workgroup's prologue/epilogue then runs under the other's MFMA loop.
+template <int BN, int WM, int WN, int NSTAGE, int EPI>
+__global__ __launch_bounds__(WM * WN * 64, 2)
 void gemm_f16_v2_kernel(GemmParams p) {
+    constexpr int V2_THREADS = WM * WN * 64;
     constexpr int BM = V2_BM, BK = V2_BK;
     constexpr int TM = BM / WM / 32;            // MFMA tiles per wave along m
     constexpr int TN = BN / WN / 32;            // along n
@@ -45,7 +49,6 @@ void gemm_f16_v2_kernel(GemmParams p) {
     constexpr int A_ROUNDS = BM * SLOTS / V2_THREADS;   // DMA instructions per thread per K tile
     constexpr int B_ROUNDS = BN * SLOTS / V2_THREADS;
     constexpr int G = A_ROUNDS + B_ROUNDS;
-    constexpr int NSTAGE = V2_NSTAGE;
     constexpr int BUF_ELEMS = (BM + BN) * BK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     f16* lds = reinterpret_cast<f16*>(smem_raw);
@@ -68,7 +71,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    constexpr int BW = 4;
+    constexpr int BW = 1024 / BN;             // band of n-tiles that share an A panel on one XCD
     const int full_tiles = (ntn / BW) * BW * mtn;
     int tm, tn;
     if (t < full_tiles) {
@@ -244,7 +247,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     __syncthreads();
     constexpr int WN_COLS = TN * 32;                 // 64 for the 256x256 variant
     constexpr int PITCH = WN_COLS + 4;               // fp32 elements; +4 keeps ds_write_b128 conflict free
-    float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * PITCH + 64);
+    float* slab = reinterpret_cast<float*>(smem_raw) + wave * 2400;     // 9600 B per wave: fp32 slab 8704 B, or fp16 hi+lo slabs 2 x 4608 B
     constexpr bool F16_OUT = (EPI == EPI_F16 || EPI == EPI_GELU_F16);
     constexpr int CPL = F16_OUT ? 8 : 4;             // columns per lane on the way out
     constexpr int LPR = WN_COLS / CPL;               // lanes per row
@@ -258,41 +261,64 @@ void gemm_f16_v2_kernel(GemmParams p) {
         bias4[c] = *reinterpret_cast<const f32x4*>(p.bias + ncol + c * 4);
         if (EPI == EPI_RESID_LS) ls4[c] = *reinterpret_cast<const f32x4*>(p.ls + ncol + c * 4);
     }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
+    // fp16 outputs: bias (+GELU) and the fp16 conversion happen on the accumulator fragments, so only half
+    // the bytes cross the LDS (its ds_write rate, ~80 B/clk/CU, was a third of this epilogue)
+    constexpr int PITCH16 = WN_COLS + 8;             // fp16 elements: 144-byte rows keep ds_read_b128 aligned
+    f16* slab_hi = reinterpret_cast<f16*>(slab);
+    f16* slab_lo = slab_hi + 32 * PITCH16;
+    f32x4 bfrag[F16_OUT ? TN * 4 : 1];
+    if (F16_OUT) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                f32x4 v;
+            for (int rg = 0; rg < 4; ++rg)
+                bfrag[i * 4 + rg] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WN_COLS + i * 32 + 8 * rg + 4 * fhi);
+    }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-                *reinterpret_cast<f32x4*>(slab + frow * PITCH + i * 32 + 8 * rg + 4 * fhi) = v;
-            }
+    for (int j = 0; j < TM; ++j) {
         const int mbase = m0 + wm * (TM * 32) + j * 32;
         if (F16_OUT) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x2 a = {acc[i][j][rg * 4 + 0] + bfrag[i * 4 + rg][0], acc[i][j][rg * 4 + 1] + bfrag[i * 4 + rg][1]};
+                    f32x2 b = {acc[i][j][rg * 4 + 2] + bfrag[i * 4 + rg][2], acc[i][j][rg * 4 + 3] + bfrag[i * 4 + rg][3]};
+                    if (EPI == EPI_GELU_F16) {
+                        if (p.out_lo) { a = gelu_fast2(a); b = gelu_fast2(b); }            // strict: full-accuracy polynomial
+                        else { a = gelu_fast2_fp16(a); b = gelu_fast2_fp16(b); }
+                    }
+                    f16x4 h, l;
+                    f16 hh, ll;
+                    split_f16(a[0], hh, ll); h[0] = hh; l[0] = ll;
+                    split_f16(a[1], hh, ll); h[1] = hh; l[1] = ll;
+                    split_f16(b[0], hh, ll); h[2] = hh; l[2] = ll;
+                    split_f16(b[1], hh, ll); h[3] = hh; l[3] = ll;
+                    const int so = frow * PITCH16 + i * 32 + 8 * rg + 4 * fhi;
+                    *reinterpret_cast<f16x4*>(slab_hi + so) = h;
+                    if (p.out_lo) *reinterpret_cast<f16x4*>(slab_lo + so) = l;
+                }
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int r = it * RPI + orow_in;
                 const int m = mbase + r;
-                f32x4 x0 = *reinterpret_cast<const f32x4*>(slab + r * PITCH + ocol);
-                f32x4 x1 = *reinterpret_cast<const f32x4*>(slab + r * PITCH + ocol + 4);
-                f16x8 h, l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f32x2 ab = {x0[e] + bias4[0][e], x1[e] + bias4[CPL / 4 - 1][e]};
-                    if (EPI == EPI_GELU_F16) ab = gelu_fast2(ab);
-                    f16 hh, ll;
-                    split_f16(ab[0], hh, ll); h[e] = hh; l[e] = ll;
-                    split_f16(ab[1], hh, ll); h[4 + e] = hh; l[4 + e] = ll;
-                }
+                const f16x8 h = *reinterpret_cast<const f16x8*>(slab_hi + r * PITCH16 + ocol);
                 if (m < p.M) {
                     const int64_t o = p.out_kt > 0 ? blk_off(m, ncol, p.out_kt) : (int64_t)m * p.N + ncol;
                     *reinterpret_cast<f16x8*>(p.out_hi + o) = h;
-                    if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = l;
+                    if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = *reinterpret_cast<const f16x8*>(slab_lo + r * PITCH16 + ocol);
                 }
             }
         } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+                    *reinterpret_cast<f32x4*>(slab + frow * PITCH + i * 32 + 8 * rg + 4 * fhi) = v;
+                }
             // issue every global read of the slab first, then the math and the stores
             f32x4 res[32 / RPI];
             int64_t oo[32 / RPI];
@@ -331,25 +357,25 @@ void gemm_f16_v2_kernel(GemmParams p) {
     }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int NSTAGE>
 int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)V2_NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
+    constexpr size_t lds_bytes = (size_t)NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
     static bool attr_set = false;
     if (!attr_set) {
-#define KEEP_SET_ATTR(E) if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_v2_kernel<BN, WM, WN, E>), \
+#define KEEP_SET_ATTR(E) if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, E>), \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
         KEEP_SET_ATTR(EPI_F16) KEEP_SET_ATTR(EPI_GELU_F16) KEEP_SET_ATTR(EPI_RESID_LS) KEEP_SET_ATTR(EPI_PATCH) KEEP_SET_ATTR(EPI_RESID_F32)
 #undef KEEP_SET_ATTR
         attr_set = true;
     }
     const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM);
-    dim3 g(grid), b(V2_THREADS);
+    dim3 g(grid), b(WM * WN * 64);
     switch (epi) {
-        case EPI_F16:      hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, EPI_F16>), g, b, lds_bytes, s, p); break;
-        case EPI_GELU_F16: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, EPI_GELU_F16>), g, b, lds_bytes, s, p); break;
-        case EPI_RESID_LS: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, EPI_RESID_LS>), g, b, lds_bytes, s, p); break;
-        case EPI_PATCH:    hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, EPI_PATCH>), g, b, lds_bytes, s, p); break;
-        default:           hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, EPI_RESID_F32>), g, b, lds_bytes, s, p); break;
+        case EPI_F16:      hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_F16>), g, b, lds_bytes, s, p); break;
+        case EPI_GELU_F16: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_GELU_F16>), g, b, lds_bytes, s, p); break;
+        case EPI_RESID_LS: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_RESID_LS>), g, b, lds_bytes, s, p); break;
+        case EPI_PATCH:    hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_PATCH>), g, b, lds_bytes, s, p); break;
+        default:           hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_RESID_F32>), g, b, lds_bytes, s, p); break;
     }
     return 0;
 }
@@ -357,10 +383,14 @@ int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
 }  // namespace keepk
 
 // returns 0 if launched, 1 if the shape is not covered by this variant
+//   variant 256  : 256x256 tiles, 8 waves, one workgroup per CU
+//   variant 128  : 256x128 tiles, 8 waves (64x64 per wave)
+//   variant 2128 : 256x128 tiles, 4 waves (128x64 per wave), two workgroups per CU
 int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s) {
     using namespace keepk;
     if (p.K % V2_BK) return 1;
-    if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4>(p, epi, s);
-    if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2>(p, epi, s);
+    if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
+    if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
+    if (variant == 2128 && p.N % 128 == 0) return launch_v2<128, 2, 2, 3>(p, epi, s);
     return 1;
 }

@@ -27,7 +27,7 @@ GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 40
                (2048, 1024, 1024), (1000, 256, 192)]
 
 
-@pytest.fixture(params=[1, 128, 256], ids=["v1_128x128", "v2_256x128", "v2_256x256"])
+@pytest.fixture(params=[1, 128, 256, 2128], ids=["v1_128x128", "v2_256x128", "v2_256x256", "v2_256x128_2wg"])
 def gemm_impl(ops, request):
     """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile)."""
     ops.set_option("gemm_impl", request.param)
@@ -100,6 +100,15 @@ def test_gelu_epilogue_accuracy_sweep(ops, gemm_impl):
     out = ops.linear(a, xs, torch.zeros(N), EPI_GELU_F16, True).cpu().double()     # split: fp32-class output
     ref = gelu64(xs.double()).t()
     assert (out - ref).abs().max() < 2e-6
+
+
+def test_gelu_epilogue_fp16_mode_sweep(ops, gemm_impl):
+    """Single-pass mode uses the degree-6 polynomial; its error must stay under the fp16 rounding of the output."""
+    M, N, K = 256, 256, 256
+    xs = torch.linspace(-6, 6, N * K).reshape(N, K)
+    out = ops.linear(torch.eye(M, K), xs, torch.zeros(N), EPI_GELU_F16, False).cpu().double()
+    ref = gelu64(r16(xs)).t()
+    assert ((out - ref).abs() <= 5e-4 * ref.abs() + 3e-6).all()
 
 
 def test_linear_rejects_bad_shapes(ops):
