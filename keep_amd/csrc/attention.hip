@@ -64,28 +64,37 @@ __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok,
                                              (att_lptr_t)(sK + (it * ATT_THREADS + wave * 64) * 8), 16, 0, 0);
         }
     }
-    uint4 va[V_IT], vb[V_IT];
+    // V^T: work item = (key pair kp, 16-byte chunk c).  A wavefront takes 64 consecutive key pairs of ONE
+    // chunk, so its 8 transposed stores (one per feature of the chunk) each write 64 consecutive dwords of
+    // one V^T row: conflict-free without any data-dependent register selection (the first version rotated
+    // the element order per lane with a select chain, which the compiler turned into ~200 exec-mask
+    // branches -- the kernel was VALU-issue bound on its own staging code).
+    constexpr int NPAIR_PAD = (NPAIR + 63) / 64 * 64;
+    constexpr int V_IT2 = NPAIR_PAD * 8 / ATT_THREADS;
+    uint4 va[V_IT2], vb[V_IT2];
 #pragma unroll
-    for (int it = 0; it < V_IT; ++it) {
-        int idx = tid + it * ATT_THREADS;
-        idx = idx < V_ITEMS ? idx : V_ITEMS - 1;           // clamped duplicates rewrite identical bytes
-        const int kp = idx >> 3, c = idx & 7;
+    for (int it = 0; it < V_IT2; ++it) {
+        const int idx = tid + it * ATT_THREADS;
+        const int c = idx / NPAIR_PAD;
+        int kp = idx % NPAIR_PAD;
+        kp = kp < NPAIR ? kp : NPAIR - 1;
         const int r0 = 2 * kp < ntok ? 2 * kp : ntok - 1, r1 = 2 * kp + 1 < ntok ? 2 * kp + 1 : ntok - 1;
         va[it] = *reinterpret_cast<const uint4*>(base + (int64_t)r0 * D3 + voff + c * 8);
         vb[it] = *reinterpret_cast<const uint4*>(base + (int64_t)r1 * D3 + voff + c * 8);
     }
 #pragma unroll
-    for (int it = 0; it < V_IT; ++it) {
-        int idx = tid + it * ATT_THREADS;
-        idx = idx < V_ITEMS ? idx : V_ITEMS - 1;
-        const int kp = idx >> 3, c = idx & 7;
+    for (int it = 0; it < V_IT2; ++it) {
+        const int idx = tid + it * ATT_THREADS;
+        const int c = idx / NPAIR_PAD, kp = idx % NPAIR_PAD;
+        if (kp < NPAIR) {
+            const unsigned wa[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
+            const unsigned wb[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int e = (r + c) & 7;                  // rotate so the 8 lanes of a key pair hit 8 banks
-            const unsigned wa = sel4(va[it], e >> 1), wb = sel4(vb[it], e >> 1);
-            const int sh = (e & 1) * 16;
-            const unsigned packed = ((wa >> sh) & 0xffffu) | (((wb >> sh) & 0xffffu) << 16);
-            *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * VS + 2 * kp) = packed;
+            for (int e = 0; e < 8; ++e) {
+                const int sh = (e & 1) * 16;
+                const unsigned packed = ((wa[e >> 1] >> sh) & 0xffffu) | (((wb[e >> 1] >> sh) & 0xffffu) << 16);
+                *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * VS + 2 * kp) = packed;
+            }
         }
     }
 }
@@ -118,12 +127,15 @@ void attention_kernel(AttnParams p) {
         float bias = 0.f;
         if (k >= ntok) bias = -INFINITY;
         else if (p.mask && p.mask[tok0 + k] == 0) bias = -1e30f;     // HF adds finfo.min to masked keys
-        sBias[k] = bias;
+        sBias[k] = bias;                                             // (scores live in the log2 domain below; -1e30 / -inf are scale-free)
     }
+    // The K tiles arrive by LDS-DMA: nothing but this wave's own vmcnt orders them before the barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int qi = lane & 15, g = lane >> 4;
     const int nqt = (ntok + 15) >> 4;
+    const float sc2 = p.scale * 1.4426950408889634f;
     // Q fragments of the next query tile are fetched while the current one is computed
     f16x8 qn[2], qln[2];
     auto load_q = [&](int qt) {
@@ -180,7 +192,7 @@ void attention_kernel(AttnParams p) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + kt * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[kt][r] = s[kt][r] * p.scale + bias[r];
+                s[kt][r] = s[kt][r] * sc2 + bias[r];           // log2-domain score: exp(x) = exp2(x * log2 e)
                 mx = fmaxf(mx, s[kt][r]);
             }
             if ((kt & 3) == 3) KEEP_MEM_BARRIER();
@@ -192,7 +204,7 @@ void attention_kernel(AttnParams p) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
                 s[kt][r] = e;
                 sum += e;
             }
