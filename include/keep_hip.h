@@ -86,6 +86,8 @@ int keep_bert_layers(keep_handle* h);
  *   "streams"         concurrent sub-batches inside keep_encode_image (default 2, 1..4): the batch is split
  *                     into that many lanes on internal HIP streams, issued layer-interleaved, and joined
  *                     back onto the caller's stream with events (no host synchronisation)
+ *   "cls_tail"        1 (default): in the last ViT block run proj / MLP for the CLS rows only (exact: the
+ *                     pooled output reads nothing else); 0: evaluate every token as the reference does
  *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256: 256xBN LDS-DMA variant
  *                     (process-wide kernel selection override, for tests and A/B measurements)
  */

@@ -134,7 +134,8 @@ void attention_kernel(AttnParams p) {
     __syncthreads();
 
     const int qi = lane & 15, g = lane >> 4;
-    const int nqt = (ntok + 15) >> 4;
+    const int nq = (p.q_rows > 0 && p.q_rows < ntok) ? p.q_rows : ntok;
+    const int nqt = (nq + 15) >> 4;
     const float sc2 = p.scale * 1.4426950408889634f;
     // Q fragments of the next query tile are fetched while the current one is computed
     f16x8 qn[2], qln[2];
@@ -258,7 +259,7 @@ void attention_kernel(AttnParams p) {
             }
         }
 #undef KEEP_MEM_BARRIER
-        if (q < ntok) {
+        if (q < nq) {
             const int mrow = (int)(tok0 + q);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {

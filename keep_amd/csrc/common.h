@@ -98,6 +98,7 @@ struct AttnParams {
     int out_kt;
     const int64_t* mask;                  // [batch][ntok] (1 = attend) or nullptr
     int batch, ntok, heads;               // head_dim fixed at 64
+    int q_rows;                           // > 0: only the first q_rows query rows of every image are computed (CLS-only last block)
     int split;                            // 0/1
     float scale;                          // 1/sqrt(64)
 };
@@ -145,6 +146,8 @@ void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const flo
                           int P, int T, int D, int vocab, int type_vocab,
                           float* resid, f16* out_hi, f16* out_lo /* blk layout */, int* err_flag, hipStream_t s);
 void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s);
+// blk-layout fp16 [*, D]: dst row r <- src row r * row_stride
+void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, int D, hipStream_t s);
 
 // wsi.hip
 void launch_group_top2(const float* logits, int n, int K, int C, float* partial, int max_row_blocks, float* sums, hipStream_t s);

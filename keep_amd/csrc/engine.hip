@@ -73,6 +73,7 @@ struct keep_handle {
     int strict_blocks = 0;
     int max_tiles = 256;
     int max_prompts = 64;
+    int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
     int n_streams = 2;           // concurrent sub-batches inside keep_encode_image (1 = everything on the caller's stream)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -171,13 +172,16 @@ struct Carver {
     template <typename T> T* take(size_t n) { T* p = reinterpret_cast<T*>(base + off); off += align_up(n * sizeof(T)); return p; }
 };
 
-struct VitWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo, *pat_hi, *pat_lo; float *cls, *h1; };
+struct VitWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo, *pat_hi, *pat_lo; float *cls, *h1;
+               // compact CLS-row buffers for the last block
+               float* c_resid; f16 *c_att_hi, *c_att_lo, *c_xn_hi, *c_xn_lo, *c_mlp_hi, *c_mlp_lo; };
 struct TxtWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; };
 
 size_t vit_ws_bytes(const keep_handle* h, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F, k = split ? 2 : 1;
     return align_up(M * D * 4) + k * (align_up(blk_elems(M, D) * 2) * 2 + align_up(M * 3 * D * 2) + align_up(blk_elems(M, F) * 2)) + 2 * align_up(blk_elems(Mp, 768) * 2) +
-           align_up((size_t)Bc * D * 4) + align_up((size_t)Bc * h->proj_dim * 4) + 4096;
+           align_up((size_t)Bc * D * 4) + align_up((size_t)Bc * h->proj_dim * 4) + 4096 +
+           align_up((size_t)Bc * D * 4) + 2 * (2 * align_up(blk_elems(Bc, D) * 2) + align_up(blk_elems(Bc, F) * 2));
 }
 VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F;
@@ -190,6 +194,10 @@ VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
     w.pat_hi = c.take<f16>(blk_elems(Mp, 768)); w.pat_lo = c.take<f16>(blk_elems(Mp, 768));
     w.cls = c.take<float>((size_t)Bc * D);
     w.h1 = c.take<float>((size_t)Bc * h->proj_dim);
+    w.c_resid = c.take<float>((size_t)Bc * D);
+    w.c_att_hi = c.take<f16>(blk_elems(Bc, D)); w.c_att_lo = c.take<f16>(blk_elems(Bc, D));
+    w.c_xn_hi = c.take<f16>(blk_elems(Bc, D));  w.c_xn_lo = c.take<f16>(blk_elems(Bc, D));
+    w.c_mlp_hi = c.take<f16>(blk_elems(Bc, F)); w.c_mlp_lo = c.take<f16>(blk_elems(Bc, F));
     return w;
 }
 size_t txt_ws_bytes(const keep_handle* h, int64_t Pc, int64_t T, bool split) {
@@ -238,7 +246,7 @@ GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M
 // concurrently and issues their kernels layer-interleaved, so one lane's memory-bound phases (LayerNorm,
 // attention staging, GEMM epilogues, partial last rounds of workgroups) overlap the other lane's MFMA phases.
 struct VitLane {
-    const void* pixels; int pix_dtype; int Bc; float* out; hipStream_t s; VitWs ws;
+    const void* pixels; int pix_dtype; int Bc; float* out; hipStream_t s; VitWs ws; bool cls_compact = false;
 };
 
 int vit_begin(keep_handle* h, VitLane& L) {
@@ -283,34 +291,52 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
             launch_gemm_f16(p, EPI_F16, s);
         }
+        // Last block: everything after the attention is per-token and only the CLS token is pooled
+        // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
+        // Exact (same arithmetic on the rows that matter); the skipped FLOPs still count as algorithmic work.
+        const bool cls_only = (i == h->vit_depth - 1) && h->cls_tail;
         {
             Scope sc(h, T_VIT_ATTN, s);
             AttnParams a{};
             a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
             a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
+            a.q_rows = cls_only ? 1 : 0;
             if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
+        }
+        const int Mr = cls_only ? Bc : M;
+        float* resid = cls_only ? ws.c_resid : ws.resid;
+        const f16 *att_hi = ws.att_hi, *att_lo = ws.att_lo;
+        f16 *xn_hi = ws.xn_hi, *xn_lo = ws.xn_lo, *mlp_hi = ws.mlp_hi, *mlp_lo = ws.mlp_lo;
+        if (cls_only) {
+            Scope sc(h, T_VIT_HEAD, s);
+            launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
+            launch_gather_rows_blk(ws.att_hi, 197, ws.c_att_hi, Bc, D, s);
+            if (sp) launch_gather_rows_blk(ws.att_lo, 197, ws.c_att_lo, Bc, D, s);
+            att_hi = ws.c_att_hi; att_lo = ws.c_att_lo; xn_hi = ws.c_xn_hi; xn_lo = ws.c_xn_lo; mlp_hi = ws.c_mlp_hi; mlp_lo = ws.c_mlp_lo;
+            L.cls_compact = true;
         }
         {
             Scope sc(h, T_VIT_PROJ, s);
-            GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.proj, M, sp, b.proj_b);
-            p.ls = b.ls1; p.resid = ws.resid;
+            GemmParams p = gemm_params(att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
+            p.ls = b.ls1; p.resid = resid;
             launch_gemm_f16(p, EPI_RESID_LS, s);
         }
         {
             Scope sc(h, T_VIT_LN, s);
+            ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = sp ? xn_lo : nullptr;
             ln.gamma = b.n2w; ln.beta = b.n2b;
             launch_layernorm(ln, s);
         }
         {
             Scope sc(h, T_VIT_FC1, s);
-            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.fc1, M, sp, b.fc1_b);
-            p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
+            GemmParams p = gemm_params(xn_hi, xn_lo, b.fc1, Mr, sp, b.fc1_b);
+            p.out_hi = mlp_hi; p.out_lo = sp ? mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
             launch_gemm_f16(p, EPI_GELU_F16, s);
         }
         {
             Scope sc(h, T_VIT_FC2, s);
-            GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.fc2, M, sp, b.fc2_b);
-            p.ls = b.ls2; p.resid = ws.resid;
+            GemmParams p = gemm_params(mlp_hi, mlp_lo, b.fc2, Mr, sp, b.fc2_b);
+            p.ls = b.ls2; p.resid = resid;
             launch_gemm_f16(p, EPI_RESID_LS, s);
         }
     }
@@ -324,7 +350,8 @@ int vit_end(keep_handle* h, VitLane& L) {
         // final LayerNorm is per-token, global_pool='token' reads row 0 only -> normalise CLS rows only
         Scope sc(h, T_VIT_HEAD, s);
         LnParams ln{};
-        ln.x = ws.resid; ln.x_stride = (int64_t)197 * D; ln.rows = Bc; ln.D = D; ln.eps = 1e-6f;
+        ln.x = L.cls_compact ? ws.c_resid : ws.resid; ln.x_stride = L.cls_compact ? (int64_t)D : (int64_t)197 * D;
+        ln.rows = Bc; ln.D = D; ln.eps = 1e-6f;
         ln.gamma = find(h, "visual.norm.weight")->f32; ln.beta = find(h, "visual.norm.bias")->f32;
         ln.out_f32 = ws.cls; ln.out_f32_stride = D;
         launch_layernorm(ln, s);
@@ -702,6 +729,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
+    else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
     else if (n == "gemm_ablate") { g_gemm_ablate = v; }
     else if (n == "gemm_stagger_pct") { g_gemm_stagger_pct = v; }

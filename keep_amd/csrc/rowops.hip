@@ -296,8 +296,21 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_st
     dst[i] = src[(int64_t)r * src_stride + d];
 }
 
+__global__ void gather_rows_blk_kernel(const f16* __restrict__ src, int row_stride, f16* __restrict__ dst, int rows, int D) {
+    const int KT = D / 32;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte chunk (8 k) per thread
+    if (i >= (int64_t)rows * (D / 8)) return;
+    const int r = (int)(i / (D / 8)), k = (int)(i % (D / 8)) * 8;
+    *reinterpret_cast<f16x8*>(dst + blk_off(r, k, KT)) = *reinterpret_cast<const f16x8*>(src + blk_off(r * row_stride, k, KT));
+}
+
 }  // namespace keepk
 using namespace keepk;
+
+void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, int D, hipStream_t s) {
+    const int64_t n = (int64_t)rows * (D / 8);
+    hipLaunchKernelGGL(gather_rows_blk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, row_stride, dst, rows, D);
+}
 
 int launch_layernorm(const LnParams& p, hipStream_t s) {
     dim3 grid((p.rows + 3) / 4), block(256);

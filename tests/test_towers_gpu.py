@@ -143,6 +143,17 @@ def test_batch_chunking_is_invisible(small):
     assert torch.equal(m.encode_text(toks), t_full)
 
 
+def test_cls_only_tail_is_exact(small):
+    """Last block on the CLS rows only (engine option cls_tail, default on) vs every token."""
+    for precision in ("fp16", "strict"):
+        m = make_model(small, precision)
+        x = synth_tiles(6, seed=13).cuda()
+        fast = m.encode_image(x)
+        m.set_option("cls_tail", 0)
+        full = m.encode_image(x)
+        assert (fast - full).abs().max() < 2e-6
+
+
 # ------------------------------------------------------------------ full depth vs golden (HF outputs)
 @pytest.mark.parametrize("precision", ["strict", "fp16"])
 def test_full_depth_image_tower_vs_golden(golden_dir, text_bank, precision):
