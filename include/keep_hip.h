@@ -141,9 +141,11 @@ int keep_refine(keep_handle* h, const float* probs, const int64_t* coords, int64
  * "vit.head" "text.embed" "text.ln" "text.qkv" "text.attn" "text.out" "text.ffn1" "text.ffn2"
  * "text.pool" "sim".  keep_profile_enable(h, NULL) times every tag, a name times only that tag,
  * "" disables.  keep_profile_read synchronises the recorded events and returns the accumulated
- * milliseconds and launch count for `tag` since the last keep_profile_reset. */
+ * milliseconds, launch count and (for GEMM tags) executed FLOPs 2*M*N*K for `tag` since the last
+ * keep_profile_reset.  Lanes on different internal streams overlap, so per-tag times can sum to more than
+ * the wall time. */
 int keep_profile_enable(keep_handle* h, const char* tag_or_null);
-int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches);
+int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches, double* flops);
 int keep_profile_reset(keep_handle* h);
 
 /* ---- single-operator entry points (used by the parity tests; fp32 in/out on device) -----------

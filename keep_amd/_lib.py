@@ -42,7 +42,7 @@ SIGNATURES = {
     "keep_prompt_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "keep_refine": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     "keep_profile_enable": (_i32, [_vp, C.c_char_p]),
-    "keep_profile_read": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "keep_profile_read": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "keep_profile_reset": (_i32, [_vp]),
     "keep_op_linear": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "keep_op_attention": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),

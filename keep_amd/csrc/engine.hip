@@ -91,6 +91,7 @@ struct keep_handle {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double prof_ms[T_COUNT] = {0};
     int64_t prof_n[T_COUNT] = {0};
+    double prof_flops[T_COUNT] = {0};      // executed FLOPs (2*M*N*K) of the profiled GEMM launches
 
     int fail(int code, const char* fmt, ...) {
         char buf[1024];
@@ -102,6 +103,7 @@ struct keep_handle {
     bool any_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
 
     bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && tag == prof_tag); }
+    void prof_add_flops(int tag, double f) { if (prof_on(tag)) prof_flops[tag] += f; }
     void prof_begin(int tag, hipStream_t s) {
         if (!prof_on(tag)) return;
         Rec r; r.tag = tag;
@@ -231,6 +233,11 @@ int check_launch(keep_handle* h, const char* what) {
     return KEEP_OK;
 }
 
+void run_gemm(keep_handle* h, int tag, const GemmParams& p, int epi, hipStream_t s) {
+    h->prof_add_flops(tag, 2.0 * p.M * (double)p.N * p.K * p.nseg);
+    launch_gemm_f16(p, epi, s);
+}
+
 GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M, bool split, const float* bias) {
     GemmParams p{};
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w->hi; p.w_lo = w->lo;
@@ -266,7 +273,7 @@ int vit_begin(keep_handle* h, VitLane& L) {
                                    find(h, "visual.patch_embed.proj.bias")->f32);
         p.pos = find(h, "visual.pos_embed")->f32;
         p.resid = ws.resid;
-        launch_gemm_f16(p, EPI_PATCH, s);
+        run_gemm(h, T_VIT_PATCH, p, EPI_PATCH, s);
     }
     return KEEP_OK;
 }
@@ -289,7 +296,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_QKV, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-            launch_gemm_f16(p, EPI_F16, s);
+            run_gemm(h, T_VIT_QKV, p, EPI_F16, s);
         }
         // Last block: everything after the attention is per-token and only the CLS token is pooled
         // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
@@ -319,7 +326,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_PROJ, s);
             GemmParams p = gemm_params(att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
             p.ls = b.ls1; p.resid = resid;
-            launch_gemm_f16(p, EPI_RESID_LS, s);
+            run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s);
         }
         {
             Scope sc(h, T_VIT_LN, s);
@@ -331,13 +338,13 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_FC1, s);
             GemmParams p = gemm_params(xn_hi, xn_lo, b.fc1, Mr, sp, b.fc1_b);
             p.out_hi = mlp_hi; p.out_lo = sp ? mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
-            launch_gemm_f16(p, EPI_GELU_F16, s);
+            run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s);
         }
         {
             Scope sc(h, T_VIT_FC2, s);
             GemmParams p = gemm_params(mlp_hi, mlp_lo, b.fc2, Mr, sp, b.fc2_b);
             p.ls = b.ls2; p.resid = resid;
-            launch_gemm_f16(p, EPI_RESID_LS, s);
+            run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s);
         }
     }
     return KEEP_OK;
@@ -391,7 +398,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_QKV, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-            launch_gemm_f16(p, EPI_F16, s);
+            run_gemm(h, T_TXT_QKV, p, EPI_F16, s);
         }
         {
             Scope sc(h, T_TXT_ATTN, s);
@@ -405,7 +412,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_OUT, s);
             GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.o, M, sp, b.o_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
-            launch_gemm_f16(p, EPI_RESID_F32, s);
+            run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s);
         }
         LnParams ln{};
         ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
@@ -419,13 +426,13 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_FFN1, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
             p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->bert_F / 32;
-            launch_gemm_f16(p, EPI_GELU_F16, s);
+            run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s);
         }
         {
             Scope sc(h, T_TXT_FFN2, s);
             GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.d, M, sp, b.d_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
-            launch_gemm_f16(p, EPI_RESID_F32, s);
+            run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s);
         }
         {
             Scope sc(h, T_TXT_LN, s);
@@ -952,7 +959,7 @@ int keep_profile_enable(keep_handle* h, const char* tag) {
     h->prof_mode = 1; h->prof_tag = t;
     return KEEP_OK;
 }
-int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches) {
+int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches, double* flops) {
     if (!h || !tag) return KEEP_EINVAL;
     const int t = tag_by_name(tag);
     if (t < 0) return h->fail(KEEP_EINVAL, "unknown profile tag %s", tag);
@@ -960,13 +967,14 @@ int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t
     h->prof_collect();
     if (total_ms) *total_ms = h->prof_ms[t];
     if (launches) *launches = h->prof_n[t];
+    if (flops) *flops = h->prof_flops[t];
     return KEEP_OK;
 }
 int keep_profile_reset(keep_handle* h) {
     if (!h) return KEEP_EINVAL;
     hipSetDevice(h->device);
     h->prof_collect();
-    for (int i = 0; i < T_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    for (int i = 0; i < T_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; h->prof_flops[i] = 0; }
     return KEEP_OK;
 }
 

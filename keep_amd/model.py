@@ -332,9 +332,9 @@ class KEEPModel:
         _lib.check(self._handle, _lib.load().keep_profile_reset(self._handle), "profile_reset")
 
     def profile_read(self, tag: str):
-        ms, n = C.c_double(0), C.c_int64(0)
-        _lib.check(self._handle, _lib.load().keep_profile_read(self._handle, tag.encode(), C.byref(ms), C.byref(n)), tag)
-        return ms.value, n.value
+        ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+        _lib.check(self._handle, _lib.load().keep_profile_read(self._handle, tag.encode(), C.byref(ms), C.byref(n), C.byref(fl)), tag)
+        return ms.value, n.value, fl.value
 
 
 PROFILE_TAGS = ("vit.im2col", "vit.patch", "vit.ln", "vit.qkv", "vit.attn", "vit.proj", "vit.fc1", "vit.fc2",

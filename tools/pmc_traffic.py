@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+
+Units / corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced read, so it is doubled (checked
+here on kernels whose traffic is known: attention reads the 310 MB qkv tensor -> FETCH 151 MB; LayerNorm reads
+206 MB -> FETCH 99 MB; WRITE_SIZE matched the known output sizes 1:1)."""
+import csv, json, sys
+from collections import defaultdict
+
+def mean_per_kernel(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            a = acc[row["Kernel_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+    return {k: (s / n, n) for k, (s, n) in acc.items()}
+
+fetch = mean_per_kernel(sys.argv[1], "FETCH_SIZE")
+write = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
+TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1>", "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0>",
+        "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2>", "vit.attn": "attention_kernel<13, false>", "vit.ln": "layernorm_kernel<4>"}
+out = {}
+for tag, pat in TAGS.items():
+    f = [(v, n) for k, (v, n) in fetch.items() if pat in k]
+    w = [(v, n) for k, (v, n) in write.items() if pat in k]
+    if f and w:
+        out[tag] = {"kernel": pat, "fetch_kib_raw": round(f[0][0], 1), "write_kib": round(w[0][0], 1), "dispatches": f[0][1],
+                    "bytes_per_launch": round((2 * f[0][0] + w[0][0]) * 1024)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
