@@ -156,7 +156,7 @@ void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     // estimated 256x256 tile time: ~2000 cycles per 32-deep K step + ~10k cycles of prologue/epilogue
     p.stagger_cycles = (int)((2000LL * (p.K / 32) * p.nseg + 10000) * g_gemm_stagger_pct / 100);
     int impl = g_gemm_impl;
-    if ((impl != 128 && impl != 256 && impl != 2128) || (impl == 256 && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
+    if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256) || ((impl == 256 || impl == 3256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
     launch_gemm_f16_v2(p, epi, impl, s);
 }
 
