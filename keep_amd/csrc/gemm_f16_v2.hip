@@ -68,19 +68,22 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int ntn = p.N / BN;
     const int mtn = (p.M + BM - 1) / BM;
     const int nwg = gridDim.x;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     constexpr int BW = 2048 / BN;             // band of n-tiles that share an A panel on one XCD (8 tiles of 256: measured 2.5 % better than 4 on fc1)
-    const int full_tiles = (ntn / BW) * BW * mtn;
+    auto tile_of = [&](int b, int& tm_, int& tn_) {
+        const int xcd = b & 7, slot = b >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const int full_tiles = (ntn / BW) * BW * mtn;
+        if (t < full_tiles) {
+            const int band = t / (mtn * BW), rr = t - band * (mtn * BW);
+            tm_ = rr / BW; tn_ = band * BW + (rr - tm_ * BW);
+        } else {
+            const int remw = ntn % BW, rr = t - full_tiles;
+            tm_ = rr / remw; tn_ = (ntn / BW) * BW + (rr - tm_ * remw);
+        }
+    };
     int tm, tn;
-    if (t < full_tiles) {
-        const int band = t / (mtn * BW), rr = t - band * (mtn * BW);
-        tm = rr / BW; tn = band * BW + (rr - tm * BW);
-    } else {
-        const int remw = ntn % BW, rr = t - full_tiles;
-        tm = rr / remw; tn = (ntn / BW) * BW + (rr - tm * remw);
-    }
+    tile_of(blockIdx.x, tm, tn);
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
