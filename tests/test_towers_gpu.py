@@ -143,6 +143,24 @@ def test_batch_chunking_is_invisible(small):
     assert torch.equal(m.encode_text(toks), t_full)
 
 
+def test_multi_stream_lanes_match_single_stream(small):
+    """encode_image splits batches >= 64 over internal streams (layer-interleaved lanes); results must not change."""
+    m = make_model(small, "fp16")
+    x = synth_tiles(70, seed=21).cuda()
+    m.set_option("streams", 1)
+    one = m.encode_image(x)
+    for lanes in (2, 3):
+        m.set_option("streams", lanes)
+        assert torch.equal(m.encode_image(x), one)
+        assert torch.equal(m.encode_image(x[:65]), one[:65])         # uneven split
+    with torch.no_grad():
+        ref = O.encode_image(small, x[60:70].cpu())
+    assert (one[60:70].cpu() - ref).abs().max() < 2e-3
+    # results stay ordered on the caller's stream: consume them immediately on that stream
+    y = m.encode_image(x) * 2.0
+    assert torch.equal(y, one * 2.0)
+
+
 def test_cls_only_tail_is_exact(small):
     """Last block on the CLS rows only (engine option cls_tail, default on) vs every token."""
     for precision in ("fp16", "strict"):
