@@ -20,11 +20,14 @@
 
 namespace keepk {
 
-constexpr int ATT_THREADS = 256;
+constexpr int ATT_MAX_THREADS = 512;
 constexpr int HD = 64;
 
 __host__ __device__ constexpr int att_kp2(int NT) { return ((NT + 1) / 2) * 32; }
-__host__ __device__ constexpr int att_vs(int NT) { return att_kp2(NT) + 8; }          // V^T row stride (f16)
+// V^T row stride (f16).  The PV fragment reads compile to ds_read2_b64 (16-lane groups, 32 banks): with
+// KP2 + 4 the stride is 2*odd dwords (mod 32), so the 16 feature rows of a group land on 16 distinct even
+// banks -- conflict free (KP2 + 8 measured 35 % of the kernel's LDS cycles as bank conflicts).
+__host__ __device__ constexpr int att_vs(int NT) { return att_kp2(NT) + 4; }
 __host__ __device__ constexpr size_t att_lds_bytes(int NT, bool split) {
     size_t one = (size_t)NT * 16 * HD * 2 + (size_t)HD * att_vs(NT) * 2;
     return one * (split ? 2 : 1) + (size_t)NT * 16 * 4;
@@ -45,7 +48,7 @@ typedef __attribute__((address_space(3))) void* att_lptr_t;
 //         72 % of the kernel's wave-cycles were s_waitcnt).
 // Rows >= ntok are filled with a copy of the last valid row (finite values); their scores are masked
 // with -inf, so P is exactly 0 there and 0 * finite contributes nothing.
-template <int NT>
+template <int NT, int ATT_THREADS>
 __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok, int D3, int koff, int voff,
                                          f16* sK, f16* sVt, int tid, int wave) {
     constexpr int NKP = NT * 16;
@@ -70,11 +73,12 @@ __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok,
     // the element order per lane with a select chain, which the compiler turned into ~200 exec-mask
     // branches -- the kernel was VALU-issue bound on its own staging code).
     constexpr int NPAIR_PAD = (NPAIR + 63) / 64 * 64;
-    constexpr int V_IT2 = NPAIR_PAD * 8 / ATT_THREADS;
+    constexpr int V_IT2 = (NPAIR_PAD * 8 + ATT_THREADS - 1) / ATT_THREADS;
     uint4 va[V_IT2], vb[V_IT2];
 #pragma unroll
     for (int it = 0; it < V_IT2; ++it) {
-        const int idx = tid + it * ATT_THREADS;
+        int idx = tid + it * ATT_THREADS;
+        idx = idx < NPAIR_PAD * 8 ? idx : NPAIR_PAD * 8 - 1;
         const int c = idx / NPAIR_PAD;
         int kp = idx % NPAIR_PAD;
         kp = kp < NPAIR ? kp : NPAIR - 1;
@@ -86,7 +90,7 @@ __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok,
     for (int it = 0; it < V_IT2; ++it) {
         const int idx = tid + it * ATT_THREADS;
         const int c = idx / NPAIR_PAD, kp = idx % NPAIR_PAD;
-        if (kp < NPAIR) {
+        if (kp < NPAIR && idx < NPAIR_PAD * 8) {
             const unsigned wa[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
             const unsigned wb[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
 #pragma unroll
@@ -99,9 +103,12 @@ __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok,
     }
 }
 
-template <int NT, bool SPLIT>
-__global__ __launch_bounds__(ATT_THREADS, 2)
+// NW wavefronts per workgroup: 4 (two workgroups per CU by LDS) or 8 (the 13 query tiles of a ViT head are
+// spread over twice the waves: 16 waves per CU hide the LDS / exp latencies better).
+template <int NT, bool SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64, NW >= 7 ? 4 : 2)
 void attention_kernel(AttnParams p) {
+    constexpr int ATT_THREADS = NW * 64;
     constexpr int NKP = NT * 16;
     constexpr int VS = att_vs(NT);
     constexpr int NU = (NT + 1) / 2;
@@ -121,8 +128,8 @@ void attention_kernel(AttnParams p) {
     const f16* base_hi = p.qkv_hi + tok0 * D3;
     const f16* base_lo = SPLIT ? p.qkv_lo + tok0 * D3 : nullptr;
 
-    stage_kv<NT>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
-    if (SPLIT) stage_kv<NT>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
+    stage_kv<NT, ATT_THREADS>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
+    if (SPLIT) stage_kv<NT, ATT_THREADS>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
     for (int k = tid; k < NKP; k += ATT_THREADS) {
         float bias = 0.f;
         if (k >= ntok) bias = -INFINITY;
@@ -149,12 +156,12 @@ void attention_kernel(AttnParams p) {
         }
     };
     if (wave < nqt) load_q(wave);
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += NW) {
         const int q = qt * 16 + qi;
         f16x8 qf[2], ql[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; if (SPLIT) ql[ks] = qln[ks]; }
-        if (qt + 4 < nqt) load_q(qt + 4);
+        if (qt + NW < nqt) load_q(qt + NW);
         // The K / V^T fragment reads do not depend on the query tile; without the compiler barriers
         // below LICM hoists ALL of them out of the qt loop (hundreds of VGPRs -> scratch spills).
         // Each loop is software-pipelined one step deep by hand instead.
@@ -275,36 +282,38 @@ void attention_kernel(AttnParams p) {
     }
 }
 
-template <int NT, bool SPLIT>
+template <int NT, bool SPLIT, int NW>
 int launch_one(const AttnParams& p, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t bytes = att_lds_bytes(NT, SPLIT);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NT, SPLIT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NT, SPLIT, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -2;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<NT, SPLIT>), dim3(p.batch * p.heads), dim3(ATT_THREADS), bytes, s, p);
+    hipLaunchKernelGGL((attention_kernel<NT, SPLIT, NW>), dim3(p.batch * p.heads), dim3(NW * 64), bytes, s, p);
     return 0;
 }
 
 }  // namespace keepk
+
+int g_attn_waves = 8;     // wavefronts per workgroup for the unsplit 13/16-tile kernels (4 or 8)
 
 int launch_attention(const AttnParams& p, hipStream_t s) {
     using namespace keepk;
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
     if (p.split) {
-        if (nt <= 4) return launch_one<4, true>(p, s);
-        if (nt <= 8) return launch_one<8, true>(p, s);
-        if (nt <= 13) return launch_one<13, true>(p, s);
-        if (nt <= 16) return launch_one<16, true>(p, s);
+        if (nt <= 4) return launch_one<4, true, 4>(p, s);
+        if (nt <= 8) return launch_one<8, true, 4>(p, s);
+        if (nt <= 13) return launch_one<13, true, 4>(p, s);
+        if (nt <= 16) return launch_one<16, true, 4>(p, s);
         return -1;
     }
-    if (nt <= 4) return launch_one<4, false>(p, s);
-    if (nt <= 8) return launch_one<8, false>(p, s);
-    if (nt <= 13) return launch_one<13, false>(p, s);
-    if (nt <= 16) return launch_one<16, false>(p, s);
-    if (nt <= 32) return launch_one<32, false>(p, s);
+    if (nt <= 4) return launch_one<4, false, 4>(p, s);
+    if (nt <= 8) return launch_one<8, false, 4>(p, s);
+    if (nt <= 13) return g_attn_waves == 8 ? launch_one<13, false, 8>(p, s) : launch_one<13, false, 4>(p, s);
+    if (nt <= 16) return g_attn_waves == 8 ? launch_one<16, false, 8>(p, s) : launch_one<16, false, 4>(p, s);
+    if (nt <= 32) return launch_one<32, false, 4>(p, s);
     return -1;
 }
