@@ -83,7 +83,6 @@ struct GemmParams {
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
     int out_kt;                           // > 0: fp16 output in blk layout with KT = out_kt (= N/32); 0: row-major [M][N]
     int patches_per_img;                  // EPI_PATCH: 196
-    int stagger_cycles;                   // first-round workgroup b sleeps b/256 * stagger_cycles (phase-spreads the epilogues)
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
     int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
 };

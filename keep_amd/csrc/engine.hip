@@ -23,7 +23,6 @@
 extern int g_attn_waves;
 extern int g_gemm_ablate;
 extern long long* g_gemm_dbg;
-extern int g_gemm_stagger_pct;
 extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
 
 namespace {
@@ -741,7 +740,6 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
     else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); g_attn_waves = v; }
     else if (n == "gemm_ablate") { g_gemm_ablate = v; }
-    else if (n == "gemm_stagger_pct") { g_gemm_stagger_pct = v; }
     else if (n == "gemm_dbg") {
         if (v && !g_gemm_dbg) { HIPCHK(h, hipMalloc(&g_gemm_dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(g_gemm_dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
         if (!v && g_gemm_dbg) { hipFree(g_gemm_dbg); g_gemm_dbg = nullptr; }

@@ -145,7 +145,6 @@ using namespace keepk;
 int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s);
 int g_gemm_ablate = 0;
 long long* g_gemm_dbg = nullptr;
-int g_gemm_stagger_pct = 0;   // stagger span as % of the estimated tile time (0 = off)
 int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
 
 void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
@@ -153,8 +152,6 @@ void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     GemmParams p = p_in;
     p.ablate = g_gemm_ablate;
     p.dbg = g_gemm_dbg;
-    // estimated 256x256 tile time: ~2000 cycles per 32-deep K step + ~10k cycles of prologue/epilogue
-    p.stagger_cycles = (int)((2000LL * (p.K / 32) * p.nseg + 10000) * g_gemm_stagger_pct / 100);
     int impl = g_gemm_impl;
     if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256) || ((impl == 256 || impl == 3256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
     launch_gemm_f16_v2(p, epi, impl, s);

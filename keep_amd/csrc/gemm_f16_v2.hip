@@ -136,17 +136,6 @@ void gemm_f16_v2_kernel(GemmParams p) {
 
     long long t_start = 0, t_first = 0, t_loop = 0;
     if (p.dbg) t_start = __builtin_readcyclecounter();
-    // Phase spreading.  All workgroups of a round start together and take the same time, so without
-    // this every CU reaches its epilogue at the same moment: the round's whole output (e.g. 128 MB of
-    // fp32 residual read-modify-write) hits HBM in one burst while every MFMA pipe idles (measured:
-    // ~25 us of a 56 us tile).  Delaying first-round workgroup b by b/256 of a tile time spreads the
-    // epilogues evenly; later rounds inherit the spread.  Speed only: any dispatch order is correct.
-    if (p.stagger_cycles > 0 && blockIdx.x < 256) {
-        const long long t0 = __builtin_readcyclecounter();
-        const long long want = ((long long)p.stagger_cycles * (long long)blockIdx.x) >> 8;
-        while (__builtin_readcyclecounter() - t0 < want) __builtin_amdgcn_s_sleep(32);
-    }
-
     // ---- software-pipelined main loop -------------------------------------------------------------
     // Per K tile (32 deep) a wave runs two groups of TN*TM MFMAs, on fragment sets R0 (k 0..15) and R1
     // (k 16..31).  The single barrier of a step sits BETWEEN the two groups:
