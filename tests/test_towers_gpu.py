@@ -200,6 +200,23 @@ def test_full_depth_text_tower_vs_golden(golden_dir, text_bank, precision):
     assert dcos < (5e-6 if precision == "strict" else FP16_TOL)
 
 
+def test_bench_sized_batch_is_position_independent():
+    """BASELINE config 2 size (256 tiles, full depth, two internal lanes): the oracle cannot run this in seconds,
+    so use a size-independent property -- a tile's embedding must not depend on where it sits in the batch.
+    The 8 distinct tiles are oracle-checked at small batch by the tests above."""
+    sd = synth_state_dict(KEEPShape(), seed=41, text=False)
+    m = make_model(sd, "fp16")
+    base = synth_tiles(8, seed=42).to(torch.bfloat16).cuda()
+    small = m.encode_image(base)
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(43))
+    idx = (perm % 8).cuda()
+    big = m.encode_image(base[idx])
+    assert torch.equal(big, small[idx])
+    with torch.no_grad():
+        ref = O.encode_image(sd, base[:2].float().cpu())
+    assert (small[:2].cpu() - ref).norm(dim=-1).max() < 3e-3
+
+
 def test_dual_tower_similarity_full_depth():
     """Config 3 in miniature: 16 tiles x 8 prompts through both towers, sim matrix + argmax."""
     sd = synth_state_dict(KEEPShape(), seed=31)
