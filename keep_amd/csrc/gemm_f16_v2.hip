@@ -266,6 +266,22 @@ void gemm_f16_v2_kernel(GemmParams p) {
             for (int rg = 0; rg < 4; ++rg)
                 bfrag[i * 4 + rg] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * WN_COLS + i * 32 + 8 * rg + 4 * fhi);
     }
+    f32x4 res2[2][32 / RPI];
+    int64_t oo2[2][32 / RPI];
+    auto load_res = [&](int jj, f32x4 (&res)[32 / RPI], int64_t (&oo)[32 / RPI]) {
+        const int mb = m0 + wm * (TM * 32) + jj * 32;
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int m = mb + it * RPI + orow_in;
+            const int mc = m < p.M ? m : p.M - 1;
+            int prow; int64_t orow;
+            gemm_epilogue_row<EPI>(p, mc, prow, orow);
+            oo[it] = orow * p.N + ncol;
+            if (EPI == EPI_PATCH) res[it] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + ncol);
+            else res[it] = *reinterpret_cast<const f32x4*>(p.resid + oo[it]);
+        }
+    };
+    if (!F16_OUT) load_res(0, res2[0], oo2[0]);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int mbase = m0 + wm * (TM * 32) + j * 32;
@@ -311,19 +327,9 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
                     *reinterpret_cast<f32x4*>(slab + frow * PITCH + i * 32 + 8 * rg + 4 * fhi) = v;
                 }
-            // issue every global read of the slab first, then the math and the stores
-            f32x4 res[32 / RPI];
-            int64_t oo[32 / RPI];
-#pragma unroll
-            for (int it = 0; it < 32 / RPI; ++it) {
-                const int m = mbase + it * RPI + orow_in;
-                const int mc = m < p.M ? m : p.M - 1;
-                int prow; int64_t orow;
-                gemm_epilogue_row<EPI>(p, mc, prow, orow);
-                oo[it] = orow * p.N + ncol;
-                if (EPI == EPI_PATCH) res[it] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + ncol);
-                else res[it] = *reinterpret_cast<const f32x4*>(p.resid + oo[it]);
-            }
+            // the residual rows of pass j+1 are requested before pass j is finished, so the read latency of
+            // the read-modify-write hides behind the previous pass (res2 / oo2 are double-buffered by parity of j)
+            if (j + 1 < TM) load_res(j + 1, res2[(j + 1) & 1], oo2[(j + 1) & 1]);
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int r = it * RPI + orow_in;
@@ -331,11 +337,11 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] += bias4[0][e];
-                    x[e] = (EPI == EPI_RESID_LS) ? res[it][e] + ls4[0][e] * x[e] : res[it][e] + x[e];
+                    x[e] = (EPI == EPI_RESID_LS) ? res2[j & 1][it][e] + ls4[0][e] * x[e] : res2[j & 1][it][e] + x[e];
                 }
                 if (mbase + r < p.M) {
                     float* dst = (EPI == EPI_RESID_F32) ? p.out_f32 : p.resid;
-                    *reinterpret_cast<f32x4*>(dst + oo[it]) = x;
+                    *reinterpret_cast<f32x4*>(dst + oo2[j & 1][it]) = x;
                 }
             }
         }

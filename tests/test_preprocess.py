@@ -1,0 +1,46 @@
+"""Host preprocessing (reference transform, keep_inference.py:88-93) on the reference's own example tile."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from keep_amd.preprocess import IMAGENET_MEAN, IMAGENET_STD, preprocess, preprocess_batch
+
+
+def test_example_tif_is_crop_scale_normalise(golden_dir):
+    path = os.path.join(golden_dir, "example.tif")
+    img = Image.open(path).convert("RGB")
+    assert img.size == (298, 224)                      # resize(224) is the identity, crop takes columns 37..260
+    x = preprocess(path)
+    assert x.shape == (3, 224, 224) and x.dtype == torch.float32
+    raw = np.asarray(img, dtype=np.float32)[:, 37:261, :] / 255.0
+    ref = (torch.from_numpy(raw).permute(2, 0, 1) - torch.tensor(IMAGENET_MEAN)[:, None, None]) / torch.tensor(IMAGENET_STD)[:, None, None]
+    assert torch.equal(x, ref)
+    assert preprocess_batch([path, img]).shape == (2, 3, 224, 224)
+
+
+def test_resize_then_crop_shapes():
+    for w, h in ((512, 300), (300, 512), (224, 224), (100, 180)):
+        arr = (np.random.default_rng(0).random((h, w, 3)) * 255).astype(np.uint8)
+        assert preprocess(Image.fromarray(arr)).shape == (3, 224, 224)
+
+
+@pytest.mark.gpu
+def test_quick_start_plumbing_matches_oracle(golden_dir):
+    """BASELINE config 1: one tile x three prompts through both towers and the similarity."""
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.synth import synth_prompts, synth_state_dict
+    from oracle import keep_oracle as O
+    sd = synth_state_dict(small_shape(2, 2), seed=3)
+    m = KEEPModel(precision="strict")
+    m.load_state_dict(sd)
+    m.to("cuda:0").eval()
+    img = preprocess(os.path.join(golden_dir, "example.tif")).unsqueeze(0)
+    toks = synth_prompts(3, 256, seed=4)
+    sim = m.encode_image(img) @ m.encode_text(toks).T
+    with torch.no_grad():
+        ref = O.similarity(O.encode_image(sd, img), O.encode_text(sd, toks))
+    assert sim.shape == (1, 3) and (sim - ref).abs().max() < 5e-6
