@@ -161,6 +161,26 @@ def test_multi_stream_lanes_match_single_stream(small):
     assert torch.equal(y, one * 2.0)
 
 
+def test_non_default_stream_and_weight_reload(small):
+    m = make_model(small, "fp16")
+    x = synth_tiles(70, seed=5).cuda()
+    ref = m.encode_image(x)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out = m.encode_image(x)
+        doubled = out * 2                      # consumer on the same (non-default) stream
+    st.synchronize()
+    assert torch.equal(out, ref) and torch.equal(doubled, ref * 2)
+    # loading another state_dict replaces the weights in place
+    other = synth_state_dict(small_shape(2, 2), seed=6)
+    m.load_state_dict(other)
+    with torch.no_grad():
+        want = O.encode_image(other, x[:3].cpu())
+    got = m.encode_image(x[:3]).cpu()
+    assert (got - want).norm(dim=-1).max() < 3e-3 and (got - ref[:3].cpu()).abs().max() > 1e-3
+
+
 def test_cls_only_tail_is_exact(small):
     """Last block on the CLS rows only (engine option cls_tail, default on) vs every token."""
     for precision in ("fp16", "strict"):
