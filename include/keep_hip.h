@@ -38,7 +38,8 @@ enum {
 };
 
 /* pixel dtypes accepted by keep_encode_image */
-enum { KEEP_PIX_F32 = 0, KEEP_PIX_F16 = 1, KEEP_PIX_BF16 = 2 };
+enum { KEEP_PIX_F32 = 0, KEEP_PIX_F16 = 1, KEEP_PIX_BF16 = 2,   /* [B,3,224,224] NCHW, already ImageNet-normalised */
+       KEEP_PIX_U8_HWC = 3 };                                   /* [B,224,224,3] raw uint8 RGB: ToTensor + Normalize fused on the device */
 
 /* similarity modes */
 enum {
@@ -100,7 +101,8 @@ int64_t keep_workspace_bytes(keep_handle* h);
 
 /* ---- the hot path -----------------------------------------------------------------------------
  * Replaces: KEEPModel.encode_image  (quick_start/keep_inference.py:54-58)
- *   pixels: [B,3,224,224] NCHW, ImageNet-normalised, dtype per `pix_dtype`; out: fp32 [B,768],
+ *   pixels: [B,3,224,224] NCHW, ImageNet-normalised, dtype per `pix_dtype` (or raw uint8 [B,224,224,3] with
+ *   KEEP_PIX_U8_HWC: the /255 and mean/std steps of keep_inference.py:91-92 run on the device); out: fp32 [B,768],
  *   L2-normalised (F.normalize semantics). */
 int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, float* out, void* stream);
 

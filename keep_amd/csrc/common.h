@@ -154,4 +154,4 @@ void launch_scale_vec(const float* in, int n, float f, float* out, hipStream_t s
 void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
                    unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s);
 
-enum PixelDType : int { PIX_F32 = 0, PIX_F16 = 1, PIX_BF16 = 2 };
+enum PixelDType : int { PIX_F32 = 0, PIX_F16 = 1, PIX_BF16 = 2, PIX_U8_HWC = 3 };

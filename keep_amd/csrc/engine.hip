@@ -784,7 +784,7 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     if (!h) return KEEP_EINVAL;
     if (!h->finalized || !h->vit_depth) return h->fail(KEEP_ESTATE, "image tower not loaded / finalised");
     if (!pixels || !out || B < 0) return h->fail(KEEP_EINVAL, "null pointer or negative batch");
-    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_BF16) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
+    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_U8_HWC) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
     if (B == 0) return KEEP_OK;
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -806,7 +806,7 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
         HIPCHK(h, hipEventRecord(h->ev_fork, s));
         for (int l = 0; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->aux[l], h->ev_fork, 0));
     }
-    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : 2;
+    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : (pix_dtype == KEEP_PIX_U8_HWC ? 1 : 2);    // bytes per value; 3*224*224 values per tile in every layout
     for (int64_t b0 = 0; b0 < B; b0 += per * lanes) {
         VitLane L[4];
         int nl = 0;

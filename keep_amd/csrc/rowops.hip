@@ -104,6 +104,41 @@ void im2col_kernel(const void* __restrict__ pixels, int B, f16* __restrict__ out
     }
 }
 
+// uint8 HWC tiles [B,224,224,3] (what a tile extractor / PIL delivers after resize + crop): ToTensor (/255) and
+// Normalize(ImageNet mean/std) of the reference transform (keep_inference.py:91-92) are applied on the fly,
+// in the same operation order as torchvision: (x / 255 - mean) / std in fp32.
+__global__ __launch_bounds__(256)
+void im2col_u8_kernel(const unsigned char* __restrict__ pixels, int B, f16* __restrict__ out_hi, f16* __restrict__ out_lo) {
+    // one work item = 8 consecutive pixels (24 bytes) of one image row: (b, y, xc)
+    const int64_t total = (int64_t)B * 224 * 28;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 256) {
+        const int xc = (int)(it % 28);
+        const int64_t r = it / 28;
+        const int y = (int)(r % 224), b = (int)(r / 224);
+        const unsigned char* src = pixels + (((int64_t)b * 224 + y) * 224 + xc * 8) * 3;
+        const uint2 w0 = *reinterpret_cast<const uint2*>(src);          // 24 bytes = 3 x 8-byte loads (8-byte aligned: 24 | offset)
+        const uint2 w1 = *reinterpret_cast<const uint2*>(src + 8);
+        const uint2 w2 = *reinterpret_cast<const uint2*>(src + 16);
+        const unsigned wd[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+        const int py = y >> 4, ph = y & 15, px = xc >> 1, half = xc & 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f16x8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int byte = e * 3 + c;
+                const float u = (float)((wd[byte >> 2] >> ((byte & 3) * 8)) & 0xffu);
+                const float v = (u / 255.0f - mean[c]) / stdv[c];
+                f16 hh, ll; split_f16(v, hh, ll); h[e] = hh; l[e] = ll;
+            }
+            const int64_t dst = blk_off(b * 196 + py * 14 + px, c * 256 + ph * 16 + half * 8, 24);
+            *reinterpret_cast<f16x8*>(out_hi + dst) = h;
+            if (out_lo) *reinterpret_cast<f16x8*>(out_lo + dst) = l;
+        }
+    }
+}
+
 __global__ void cls_init_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ resid,
                                 int B, int D, int ntok) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,7 +362,11 @@ void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_l
     const int64_t total = (int64_t)B * 3 * 224 * 28;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (dtype == PIX_F32) hipLaunchKernelGGL(im2col_kernel<PIX_F32>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
+    if (dtype == PIX_U8_HWC) {
+        const int64_t t8 = (int64_t)B * 224 * 28;
+        int b8 = (int)((t8 + 255) / 256); if (b8 > 256 * 16) b8 = 256 * 16;
+        hipLaunchKernelGGL(im2col_u8_kernel, dim3(b8), dim3(256), 0, s, (const unsigned char*)pixels, B, out_hi, out_lo);
+    } else if (dtype == PIX_F32) hipLaunchKernelGGL(im2col_kernel<PIX_F32>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
     else if (dtype == PIX_F16) hipLaunchKernelGGL(im2col_kernel<PIX_F16>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
     else hipLaunchKernelGGL(im2col_kernel<PIX_BF16>, dim3(blocks), dim3(256), 0, s, pixels, B, out_hi, out_lo);
     const int64_t n = (int64_t)B * D;

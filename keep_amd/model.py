@@ -239,6 +239,24 @@ class KEEPModel:
         return out if src_dev == self._device else out.to(src_dev)
 
     @torch.no_grad()
+    def encode_image_uint8(self, tiles_u8: torch.Tensor) -> torch.Tensor:
+        """Raw RGB tiles, uint8 [B,224,224,3] (HWC, after the resize + centre crop of the reference transform):
+        ToTensor and Normalize (keep_inference.py:91-92) are fused into the first kernel, so the host only ships
+        150 KB per tile.  Same result as ``encode_image(normalised_float_tiles)`` up to fp32 rounding."""
+        self._ready()
+        x = tiles_u8
+        if x.dtype != torch.uint8 or x.dim() != 4 or tuple(x.shape[1:]) != (224, 224, 3):
+            raise ValueError(f"expected uint8 [B,224,224,3], got {x.dtype} {tuple(x.shape)}")
+        src_dev = x.device
+        if x.shape[0] == 0:
+            return torch.empty((0, self.config.projection_dim), dtype=torch.float32, device=src_dev)
+        xd = x.to(self._device, non_blocking=True).contiguous()
+        out = torch.empty((xd.shape[0], self.config.projection_dim), dtype=torch.float32, device=self._device)
+        _lib.check(self._handle, _lib.load().keep_encode_image(self._handle, _ptr(xd), _lib.PIX_U8_HWC, xd.shape[0], _ptr(out),
+                                                               _stream(self._device)), "encode_image_uint8")
+        return out if src_dev == self._device else out.to(src_dev)
+
+    @torch.no_grad()
     def encode_text(self, text_inputs: Mapping[str, torch.Tensor]) -> torch.Tensor:
         """keep_inference.py:60-62: normalize(text(**inputs).pooler_output, dim=-1) -> [P, 768] fp32."""
         self._ready()

@@ -44,3 +44,27 @@ def test_quick_start_plumbing_matches_oracle(golden_dir):
     with torch.no_grad():
         ref = O.similarity(O.encode_image(sd, img), O.encode_text(sd, toks))
     assert sim.shape == (1, 3) and (sim - ref).abs().max() < 5e-6
+
+
+@pytest.mark.gpu
+def test_uint8_tiles_normalised_on_device(golden_dir):
+    """raw uint8 HWC tiles, ToTensor + Normalize fused into the first kernel."""
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.synth import synth_state_dict
+    sd = synth_state_dict(small_shape(2, 1), seed=8, text=False)
+    m = KEEPModel(precision="strict")
+    m.load_state_dict(sd)
+    m.to("cuda:0")
+    img = Image.open(os.path.join(golden_dir, "example.tif")).convert("RGB").crop((37, 0, 261, 224))
+    g = torch.Generator().manual_seed(1)
+    u8 = torch.cat([torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())[None],
+                    torch.randint(0, 256, (4, 224, 224, 3), generator=g, dtype=torch.uint8)])
+    mean, std = torch.tensor(IMAGENET_MEAN)[None, :, None, None], torch.tensor(IMAGENET_STD)[None, :, None, None]
+    f32 = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std
+    assert torch.equal(f32[0], preprocess(os.path.join(golden_dir, "example.tif")))
+    a = m.encode_image_uint8(u8)
+    b = m.encode_image(f32)
+    assert (a - b).abs().max() < 2e-6
+    with pytest.raises(ValueError):
+        m.encode_image_uint8(f32)
