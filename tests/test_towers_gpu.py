@@ -96,6 +96,28 @@ def test_encode_text_2layers_vs_oracle(small, text_bank, precision):
         assert (o @ text_bank.t() - r @ text_bank.t()).abs().max() < (2e-6 if precision == "strict" else FP16_TOL)
 
 
+def test_long_and_single_inputs(small, text_bank):
+    """T = 512 (max_position_embeddings; 32-tile attention kernel), one tile, one prompt."""
+    m = make_model(small, "fp16")
+    toks = synth_prompts(2, 512, seed=17, max_len=400)
+    toks["attention_mask"][1, :] = 1
+    with torch.no_grad():
+        ref = O.encode_text(small, toks)
+    out = m.encode_text(toks)
+    assert (out @ text_bank.t() - ref @ text_bank.t()).abs().max() < FP16_TOL
+    one = {k: v[:1, :300].contiguous() for k, v in toks.items()}
+    with torch.no_grad():
+        ref1 = O.encode_text(small, one)
+    assert (m.encode_text(one) @ text_bank.t() - ref1 @ text_bank.t()).abs().max() < FP16_TOL
+    x = synth_tiles(1, seed=18)
+    with torch.no_grad():
+        refi = O.encode_image(small, x)
+    assert (m.encode_image(x) @ text_bank.t() - refi @ text_bank.t()).abs().max() < FP16_TOL
+    ms = make_model(small, "strict")
+    with pytest.raises(ValueError):
+        ms.encode_text(toks)                      # strict mode supports T <= 256
+
+
 def test_forward_and_errors(small):
     m = make_model(small, "fp16")
     x, toks = synth_tiles(2, seed=1), synth_prompts(3, 256, seed=2)
