@@ -60,6 +60,75 @@ void layernorm_kernel(LnParams p) {
     }
 }
 
+// LayerNorm with blk-layout fp16 output.  A row's D values are spread over D/32 K-slices that lie 16 KiB apart
+// in the blk layout, so a wave that normalises one row can only store 64-byte pieces.  Here a workgroup
+// normalises R rows (one per wave), parks the fp16 results in LDS and then writes, per K-slice, the R rows x 64 B
+// that ARE contiguous in the blk layout.  R = 8 keeps the LDS footprint (17 KiB) small enough to share a CU with a
+// GEMM workgroup of the other stream lane (R = 16 could not, and lost end to end what it gained in isolation).
+template <int NV, int R>
+__global__ __launch_bounds__(R * 64)
+void layernorm_blk_kernel(LnParams p) {
+    constexpr int D = NV * 256, PITCH = D + 32, KT = D / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ln_smem[];
+    f16* s_hi = reinterpret_cast<f16*>(ln_smem);
+    f16* s_lo = s_hi + R * PITCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * R;
+    {
+        const int lr = wave;
+        const int row = row0 + lr;
+        const int rc = row < p.rows ? row : p.rows - 1;
+        const float* x = p.x + (int64_t)rc * p.x_stride;
+        f32x4 v[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(x + (i * 64 + lane) * 4);
+            if (p.add) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.add + (int64_t)rc * p.x_stride + (i * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] += a[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += v[i][e];
+        }
+        const float mean = wave_sum(sum) * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] -= mean; sq += v[i][e] * v[i][e]; }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / D) + p.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + col);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + col);
+            f32x4 y; f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = v[i][e] * rstd * g[e] + bt[e];
+                f16 hh, ll; split_f16(y[e], hh, ll); h[e] = hh; l[e] = ll;
+            }
+            if (p.out_f32 && row < p.rows) *reinterpret_cast<f32x4*>(p.out_f32 + (int64_t)row * p.out_f32_stride + col) = y;
+            *reinterpret_cast<f16x4*>(s_hi + lr * PITCH + col) = h;
+            if (p.out_lo) *reinterpret_cast<f16x4*>(s_lo + lr * PITCH + col) = l;
+        }
+    }
+    __syncthreads();
+    // R rows x 4 sixteen-byte chunks per K-slice; a wave covers 64 / (4R) slices per pass
+    constexpr int SL = 64 / (4 * R);
+    const int orow = (lane >> 2) % R, ochunk = (lane & 3) * 8;
+    const int row = row0 + orow;
+    if (row < p.rows) {
+        for (int kt = wave * SL + lane / (4 * R); kt < KT; kt += R * SL) {
+            const int64_t dst = blk_off(row, kt * 32 + ochunk, KT);
+            *reinterpret_cast<f16x8*>(p.out_hi + dst) = *reinterpret_cast<const f16x8*>(s_hi + orow * PITCH + kt * 32 + ochunk);
+            if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + dst) = *reinterpret_cast<const f16x8*>(s_lo + orow * PITCH + kt * 32 + ochunk);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ im2col for the patch embed
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
@@ -347,7 +416,16 @@ void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, 
     hipLaunchKernelGGL(gather_rows_blk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, row_stride, dst, rows, D);
 }
 
+int g_ln_impl = 1;       // 1: LDS-transposed blk stores (layernorm_blk_kernel); 0: per-row stores
 int launch_layernorm(const LnParams& p, hipStream_t s) {
+    if (g_ln_impl == 1 && p.out_kt > 0 && p.out_hi && (p.D == 1024 || p.D == 768) && p.out_kt == p.D / 32) {
+        constexpr int R = 8;
+        const size_t lds = (size_t)R * (p.D + 32) * 2 * (p.out_lo ? 2 : 1);
+        dim3 g((p.rows + R - 1) / R), b(R * 64);
+        if (p.D == 1024) hipLaunchKernelGGL((layernorm_blk_kernel<4, R>), g, b, lds, s, p);
+        else hipLaunchKernelGGL((layernorm_blk_kernel<3, R>), g, b, lds, s, p);
+        return 0;
+    }
     dim3 grid((p.rows + 3) / 4), block(256);
     if (p.D == 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, p);
     else if (p.D == 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, p);
