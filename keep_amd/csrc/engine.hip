@@ -75,6 +75,7 @@ struct keep_handle {
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
+    int lane0_permille = 500;    // share of a 2-lane chunk given to lane 0 (experiments with workgroup-round packing)
     int n_streams = 2;           // concurrent sub-batches inside keep_encode_image (1 = everything on the caller's stream)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -739,6 +740,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
+    else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
     else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); g_ln_impl = v; }
     else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); g_attn_waves = v; }
     else if (n == "gemm_ablate") { g_gemm_ablate = v; }
@@ -796,7 +798,10 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     int64_t per = (B + lanes - 1) / lanes;
     if (per > h->max_tiles) per = h->max_tiles;
     const bool split = h->any_split();
-    const size_t lane_bytes = align_up(vit_ws_bytes(h, per, split));
+    const int64_t chunk_max = per * lanes;
+    const bool uneven = lanes == 2 && h->lane0_permille != 500;
+    const int64_t lane_cap = uneven ? (chunk_max * (h->lane0_permille > 500 ? h->lane0_permille : 1000 - h->lane0_permille) + 999) / 1000 : per;
+    const size_t lane_bytes = align_up(vit_ws_bytes(h, lane_cap, split));
     int rc = ensure_arena(h, lane_bytes * lanes);
     if (rc) return rc;
     if (lanes > 1) {
@@ -812,11 +817,14 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     for (int64_t b0 = 0; b0 < B; b0 += per * lanes) {
         VitLane L[4];
         int nl = 0;
+        const int64_t chunk = (B - b0) < chunk_max ? (B - b0) : chunk_max;
+        const int64_t n0 = uneven ? (chunk * h->lane0_permille + 500) / 1000 : per;
         for (int l = 0; l < lanes; ++l) {
-            const int64_t lo = b0 + l * per;
-            if (lo >= B) break;
+            const int64_t lo = b0 + (uneven ? (l ? n0 : 0) : l * per);
+            const int64_t cap = uneven ? (l ? chunk - n0 : n0) : per;
+            if (lo >= B || cap <= 0) break;
             VitLane& x = L[nl++];
-            x.Bc = (int)((B - lo) < per ? (B - lo) : per);
+            x.Bc = (int)((B - lo) < cap ? (B - lo) : cap);
             x.pixels = (const char*)pixels + (size_t)lo * 3 * 224 * 224 * px;
             x.pix_dtype = pix_dtype;
             x.out = out + lo * h->proj_dim;

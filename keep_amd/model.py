@@ -53,6 +53,8 @@ class KEEPModel:
         self._loaded = False
         self._options = {"precision": _PRECISIONS[precision], "strict_blocks": 0}
         self.check_token_ids = True
+        self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
+        self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
 
     # ------------------------------------------------------------------ lifetime
     def __del__(self):
@@ -278,6 +280,20 @@ class KEEPModel:
         ids_d = ids.to(self._device, torch.int64, non_blocking=True).contiguous()
         typ_d, msk_d = prep("token_type_ids"), prep("attention_mask")
         P, T = ids_d.shape
+        self.last_text_length = T
+        if self.trim_padding and msk_d is not None and T > 16:
+            # Columns that are padding in EVERY row change nothing (their softmax weight is exactly 0, positions are
+            # absolute, the pooler reads token 0): run the tower at the longest valid length, rounded up to 16.
+            # A row with no valid token attends uniformly over all T keys in HF, so such a batch is left alone.
+            valid = msk_d != 0
+            col = torch.nonzero(valid.any(dim=0)).flatten()
+            info = torch.stack([col[-1] + 1 if col.numel() else torch.zeros((), dtype=torch.int64, device=self._device),
+                                (~valid.any(dim=1)).any().to(torch.int64)]).tolist()
+            L = min(T, max(16, -(-info[0] // 16) * 16))
+            if info[1] == 0 and L < T:
+                ids_d, msk_d = ids_d[:, :L].contiguous(), msk_d[:, :L].contiguous()
+                typ_d = typ_d[:, :L].contiguous() if typ_d is not None else None
+                T = self.last_text_length = L
         out = torch.empty((P, self.config.text.hidden_size), dtype=torch.float32, device=self._device)
         lib = _lib.load()
         st = _stream(self._device)

@@ -96,6 +96,33 @@ def test_encode_text_2layers_vs_oracle(small, text_bank, precision):
         assert (o @ text_bank.t() - r @ text_bank.t()).abs().max() < (2e-6 if precision == "strict" else FP16_TOL)
 
 
+def test_padding_trim_is_invisible(small, text_bank):
+    """encode_text runs at the longest valid length (2.7 of 45.9 GFLOP at length 16); the result
+    must equal the padded computation, and a batch holding a row with NO valid token (HF: uniform attention over all
+    T keys) must not be trimmed."""
+    m = make_model(small, "strict")
+    toks = synth_prompts(5, 256, seed=21)                  # valid lengths 8..32
+    with torch.no_grad():
+        ref = O.encode_text(small, toks)
+    out = m.encode_text(toks)
+    assert m.last_text_length == 32 or m.last_text_length == 16
+    m.trim_padding = False
+    full = m.encode_text(toks)
+    assert m.last_text_length == 256
+    assert (out - full).abs().max() < 1e-6 and (out - ref).abs().max() < 5e-6
+    m.trim_padding = True
+    toks["attention_mask"][2, :] = 0                        # fully masked row
+    with torch.no_grad():
+        ref0 = O.encode_text(small, toks)
+    out0 = m.encode_text(toks)
+    assert m.last_text_length == 256 and (out0 - ref0).abs().max() < 5e-6
+    toks["attention_mask"][2, 200] = 1                      # a hole-y mask: only trailing all-padding columns go
+    with torch.no_grad():
+        ref1 = O.encode_text(small, toks)
+    out1 = m.encode_text(toks)
+    assert m.last_text_length == 208 and (out1 - ref1).abs().max() < 5e-6
+
+
 def test_long_and_single_inputs(small, text_bank):
     """T = 512 (max_position_embeddings; 32-tile attention kernel), one tile, one prompt."""
     m = make_model(small, "fp16")
