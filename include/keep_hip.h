@@ -131,6 +131,21 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
 int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, int64_t N, int64_t K, int64_t C,
                        int64_t D, float* scores_out, void* stream);
 
+/* ---- tile-level zero-shot evaluation ------------------------------------------
+ * Replaces the 50-round loop of training/path_training/zero_shot.py:124-136 (per round: one numpy GEMM
+ * `image_embeddings.dot(each_round.T)` + a Python argmax per tile).  feats fp32 [N,D] L2-normalised (zero_shot.py:
+ * 121-122), bank fp32 [K*C, D]: round k's C normalised class embeddings in rows k*C..k*C+C-1.
+ * labels_out int32 [N,K] (device): argmax class of tile n in round k, first maximum wins (numpy.argmax). */
+int keep_group_argmax(keep_handle* h, const float* feats, const float* bank, int64_t N, int64_t K, int64_t C,
+                      int64_t D, int32_t* labels_out, void* stream);
+
+/* Replaces the retrieval loop of zero_shot.py:168-171 + retrieval_metrics (zeroshot_metrics.py:6-17).
+ * txt fp32 [P,D], img fp32 [N,D], both L2-normalised; target int32 [P] = the image each text must retrieve
+ * (NULL: text t -> image t, as the reference).  rank_out int32 [P] (device) = position of the target in the
+ * descending score list (0 = best; equal scores: higher index first); p@k = mean(rank < k). */
+int keep_retrieval_rank(keep_handle* h, const float* txt, const float* img, int64_t P, int64_t N, int64_t D,
+                        const int32_t* target, int32_t* rank_out, void* stream);
+
 /* Replaces `refine_seg` (subtyping_utils.py:38-65, detection_utils.py:39-74, segment_utils.py:63-89).
  * probs fp32 [N,C] (softmax(10*cos)), coords int64 [N,2].  out_mean fp32 [N,C]: for the first tile of
  * every distinct coordinate, the float32 mean of the existing tiles among (x-p,y-p),(x,y-p),(x-p,y),(x,y)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "keep_token_error": (_i32, [_vp, _vp]),
     "keep_similarity": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp]),
     "keep_prompt_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "keep_group_argmax": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "keep_retrieval_rank": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "keep_refine": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp]),
     "keep_profile_enable": (_i32, [_vp, C.c_char_p]),
     "keep_profile_read": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),

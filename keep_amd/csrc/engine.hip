@@ -944,6 +944,56 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
     return check_launch(h, "prompt_scores");
 }
 
+int keep_group_argmax(keep_handle* h, const float* feats, const float* bank, int64_t N, int64_t K, int64_t C, int64_t D,
+                      int32_t* labels_out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!feats || !bank || !labels_out || N < 1 || K < 1 || C < 1 || D < 16 || D % 16) return h->fail(KEEP_EINVAL, "bad group_argmax arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scope sc(h, T_SIM, s);
+    const int64_t KC = K * C;
+    int64_t chunk = ((int64_t)256 << 20) / (KC * 4);
+    if (chunk < 256) chunk = 256;
+    if (chunk > N) chunk = N;
+    int rc = ensure_arena(h, align_up((size_t)chunk * KC * 4));
+    if (rc) return rc;
+    float* logits = (float*)h->arena;
+    for (int64_t r0 = 0; r0 < N; r0 += chunk) {
+        const int64_t n = (N - r0) < chunk ? (N - r0) : chunk;
+        SgemmParams g{};
+        g.a = feats + r0 * D; g.lda = D; g.b = bank; g.ldb = D; g.out = logits; g.ldo = KC; g.bias = nullptr;
+        g.M = (int)n; g.N = (int)KC; g.K = (int)D; g.scale = 1.0f; g.act = ACT_NONE;
+        if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "group_argmax shape");
+        // [n][K][C] is contiguous: one argmax per (tile, round) row of C scores, first maximum wins (numpy.argmax)
+        launch_row_argmax(logits, (int)(n * K), (int)C, labels_out + r0 * K, s);
+    }
+    return check_launch(h, "group_argmax");
+}
+
+int keep_retrieval_rank(keep_handle* h, const float* txt, const float* img, int64_t P, int64_t N, int64_t D,
+                        const int32_t* target, int32_t* rank_out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!txt || !img || !rank_out || P < 1 || N < 1 || D < 16 || D % 16 || (!target && P > N)) return h->fail(KEEP_EINVAL, "bad retrieval_rank arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Scope sc(h, T_SIM, s);
+    int64_t chunk = ((int64_t)256 << 20) / (N * 4);
+    if (chunk < 64) chunk = 64;
+    if (chunk > P) chunk = P;
+    int rc = ensure_arena(h, align_up((size_t)chunk * N * 4));
+    if (rc) return rc;
+    float* sim = (float*)h->arena;
+    for (int64_t r0 = 0; r0 < P; r0 += chunk) {
+        const int64_t n = (P - r0) < chunk ? (P - r0) : chunk;
+        SgemmParams g{};
+        g.a = txt + r0 * D; g.lda = D; g.b = img; g.ldb = D; g.out = sim; g.ldo = N; g.bias = nullptr;
+        g.M = (int)n; g.N = (int)N; g.K = (int)D; g.scale = 1.0f; g.act = ACT_NONE;
+        if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "retrieval_rank shape");
+        launch_diag_rank(sim, (int)n, (int)N, target, (int)r0, rank_out, s);
+    }
+    return check_launch(h, "retrieval_rank");
+}
+
 int keep_refine(keep_handle* h, const float* probs, const int64_t* coords, int64_t N, int64_t C, int64_t patch, int overlap,
                 float* out_mean, int32_t* is_first, void* stream) {
     if (!h) return KEEP_EINVAL;

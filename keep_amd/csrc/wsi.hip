@@ -103,8 +103,33 @@ __global__ void scale_vec_kernel(const float* __restrict__ in, int n, float f, f
     if (i < n) out[i] = in[i] * f;
 }
 
+// Retrieval rank of the target column (training/path_training/zero_shot.py:168-171 + retrieval_metrics): how many
+// images score above image `target[row]` for text `row`.  `arr.argsort()[-50:][::-1]` lists equal scores with the
+// higher index first, so an equal score at a higher index also counts as "above".  One workgroup per text row.
+__global__ __launch_bounds__(256)
+void diag_rank_kernel(const float* __restrict__ sim, int n_img, const int* __restrict__ target, int row0, int* __restrict__ rank) {
+    const int row = blockIdx.x;
+    const float* r = sim + (int64_t)row * n_img;
+    const int t = target ? target[row0 + row] : row0 + row;
+    const float st = r[t];
+    int cnt = 0;
+    for (int j = threadIdx.x; j < n_img; j += 256) {
+        const float v = r[j];
+        cnt += (v > st) || (v == st && j > t);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    __shared__ int part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) rank[row0 + row] = part[0] + part[1] + part[2] + part[3];
+}
+
 }  // namespace keepk
 using namespace keepk;
+
+void launch_diag_rank(const float* sim, int rows, int n_img, const int* target, int row0, int* rank, hipStream_t s) {
+    hipLaunchKernelGGL(diag_rank_kernel, dim3(rows), dim3(256), 0, s, sim, n_img, target, row0, rank);
+}
 
 void launch_scale_vec(const float* in, int n, float f, float* out, hipStream_t s) {
     hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, n, f, out);

@@ -298,3 +298,69 @@ def build_classifier(text_embeddings: Tensor) -> Tensor:
         e = F.normalize(e[None], dim=-1).mean(0)
         cols.append(e / e.norm())
     return torch.stack(cols, dim=1)
+
+
+# --------------------------------------------------------------------------
+# tile-level zero-shot evaluation protocol (training/path_training/zero_shot.py:91-139, 141-176, 215-232;
+# metrics training/path_open_clip/zeroshot_metrics.py:6-17, :31).  numpy, as the reference.
+# --------------------------------------------------------------------------
+def label2cap(prompts: Mapping) -> Dict[str, List[str]]:
+    """zero_shot.py:49-62 on the parsed prompt JSON: per class name, the 50 filled captions."""
+    out: Dict[str, List[str]] = {}
+    for type_name in list(prompts["0"]["classnames"].keys()):
+        out[type_name] = [prompts[str(i)]["templates"].replace("CLASSNAME", prompts[str(i)]["classnames"][type_name])
+                          for i in range(50)]
+    return out
+
+
+def weighted_f1(y_true: Sequence, y_pred: Sequence) -> float:
+    """sklearn.metrics.f1_score(average='weighted') (zeroshot_metrics.py:31): per-class F1 over the labels present
+    in y_true or y_pred, 0 where undefined, weighted by the class's count in y_true."""
+    labels = sorted(set(y_true) | set(y_pred))
+    yt, yp = np.asarray(y_true), np.asarray(y_pred)
+    f, w = [], []
+    for c in labels:
+        tp = float(np.sum((yt == c) & (yp == c)))
+        fp = float(np.sum((yt != c) & (yp == c)))
+        fn = float(np.sum((yt == c) & (yp != c)))
+        den = 2 * tp + fp + fn
+        f.append(2 * tp / den if den else 0.0)
+        w.append(tp + fn)
+    return float(np.average(np.array(f), weights=np.array(w)))
+
+
+def tile_classification_rounds(image_embeddings: np.ndarray, cap_embeddings: Mapping[str, np.ndarray],
+                               label_list: Sequence) -> np.ndarray:
+    """zero_shot.py:118-139: image features re-normalised in numpy; for each of the 50 prompt rounds the class
+    embeddings are row i of every class's caption embeddings, normalised; prediction = argmax of the float32
+    dot products; WF1 per round."""
+    img = np.array(image_embeddings)
+    img = img / np.linalg.norm(img, axis=1, keepdims=True)
+    names = list(cap_embeddings.keys())
+    out = []
+    for i in range(50):
+        rnd = np.array([cap_embeddings[n][i, :] for n in names])
+        rnd = rnd / np.linalg.norm(rnd, axis=1, keepdims=True)
+        score = img.dot(rnd.T)
+        pred = [names[int(np.argmax(s))] for s in score]
+        out.append(weighted_f1(list(label_list), pred))
+    return np.array(out)
+
+
+def wf1_quartiles(val_cls: np.ndarray) -> Dict[str, float]:
+    """zero_shot.py:216-222 (np.percentile(..., interpolation='midpoint'))."""
+    q1, med, q3 = np.percentile(val_cls, (25, 50, 75), method="midpoint")
+    return {"zeroshot-cls-WF1-median": float(med), "zeroshot-cls-WF1-Q1": float(q1), "zeroshot-cls-WF1-Q3": float(q3)}
+
+
+def retrieval_p_at_k(image_embeddings: np.ndarray, text_embeddings: np.ndarray) -> Dict[str, float]:
+    """zero_shot.py:161-176 + retrieval_metrics: text t's target is image t; hit when t is among the 10 / 50 most
+    similar images."""
+    img = np.array(image_embeddings); img = img / np.linalg.norm(img, axis=1, keepdims=True)
+    txt = np.array(text_embeddings); txt = txt / np.linalg.norm(txt, axis=1, keepdims=True)
+    p10 = p50 = 0
+    for t, tb in enumerate(txt):
+        best = tb.dot(img.T).argsort()[-50:][::-1]
+        p10 += int(t in best[:10])
+        p50 += int(t in best[:50])
+    return {"p@10": p10 / len(img), "p@50": p50 / len(img)}

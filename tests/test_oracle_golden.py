@@ -87,6 +87,41 @@ def test_wsi_host_logic_matches_reference_outputs(golden_dir):
     assert np.abs(probs - g["seg_probs"]).max() < 1e-6
 
 
+def test_tile_eval_protocol_matches_reference_outputs(golden_dir):
+    """oracle restatement of training/path_training/zero_shot.py vs the result dict the reference itself produced."""
+    import json
+    g = np.load(os.path.join(golden_dir, "tile_eval.npz"))
+    names = [str(n) for n in g["names"]]
+    labels = [str(x) for x in g["labels"]]
+    val = O.tile_classification_rounds(g["img"], {n: g["caps"][i] for i, n in enumerate(names)}, labels)
+    assert np.abs(val - g["wf1_rounds"]).max() < 1e-12
+    q = O.wf1_quartiles(val)
+    assert abs(q["zeroshot-cls-WF1-median"] - float(g["wf1_median"])) < 1e-12
+    assert abs(q["zeroshot-cls-WF1-Q1"] - float(g["wf1_q1"])) < 1e-12 and abs(q["zeroshot-cls-WF1-Q3"] - float(g["wf1_q3"])) < 1e-12
+    r = O.retrieval_p_at_k(g["ret_img"], g["ret_txt"])
+    assert r["p@10"] == float(g["p10"]) and r["p@50"] == float(g["p50"])
+    caps = O.label2cap(json.loads(str(g["prompts"])))
+    assert list(caps) == names and all(len(v) == 50 for v in caps.values())
+
+
+def test_weighted_f1_is_sklearns():
+    """zeroshot_metrics.py:31 calls sklearn; the restatement and the confusion-matrix form used on the GPU side agree
+    with it, including labels that are only predicted or only true."""
+    from sklearn.metrics import f1_score
+    from keep_amd.tile_eval import weighted_f1_from_confusion
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        n, c = int(rng.integers(5, 200)), int(rng.integers(2, 7))
+        yt = rng.integers(0, c, n); yp = rng.integers(0, c + (trial % 2), n)
+        if trial % 3 == 0:
+            yt[yt == 0] = 1                                   # class 0 only predicted
+        ref = f1_score(yt, yp, average="weighted", zero_division=0)
+        assert abs(O.weighted_f1(list(yt), list(yp)) - ref) < 1e-12
+        A = c + 1
+        conf = np.bincount(yt * A + yp, minlength=A * A).reshape(A, A)
+        assert abs(weighted_f1_from_confusion(conf) - ref) < 1e-12
+
+
 def test_flop_model_matches_survey():
     from keep_amd.config import bert_flops_per_prompt, vit_flops_per_tile
     assert vit_flops_per_tile() == 123_110_129_664

@@ -212,10 +212,129 @@ def golden_wsi(seed: int = 7):
                         seg_keys=seg_keys, seg_probs=seg_vals)
 
 
+def import_reference_tile_eval():
+    """training/path_training/zero_shot.py as shipped.  Its package imports (`path_open_clip`: timm/open_clip model
+    code that does not import here) are replaced by a stub package that carries the REAL metric functions of
+    training/path_open_clip/zeroshot_metrics.py; `.precision` is the real module."""
+    import importlib.util
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    tr = os.path.join(REF, "training")
+    metrics = load("_ref_zeroshot_metrics", os.path.join(tr, "path_open_clip", "zeroshot_metrics.py"))
+    poc = types.ModuleType("path_open_clip")
+    poc.__path__ = []
+    for n in ("get_input_dtype", "get_tokenizer", "build_zero_shot_classifier"):
+        setattr(poc, n, lambda *a, **k: None)
+    poc.IMAGENET_CLASSNAMES, poc.OPENAI_IMAGENET_TEMPLATES = [], []
+    poc.retrieval_metrics, poc.classification_metrics = metrics.retrieval_metrics, metrics.classification_metrics
+    tok = types.ModuleType("path_open_clip.tokenizer")
+    tok.tokenize = lambda *a, **k: None
+    sys.modules["path_open_clip"], sys.modules["path_open_clip.tokenizer"] = poc, tok
+    pkg = types.ModuleType("path_training")
+    pkg.__path__ = [os.path.join(tr, "path_training")]
+    sys.modules["path_training"] = pkg
+    load("path_training.precision", os.path.join(tr, "path_training", "precision.py"))
+    return load("path_training.zero_shot", os.path.join(tr, "path_training", "zero_shot.py"))
+
+
+def golden_tile_eval(seed: int = 9):
+    """Runs the reference's zero_shot_eval on synthetic embeddings through a stand-in model object (encode_image /
+    encode_text / __call__ return pre-drawn features; the encoders themselves are pinned elsewhere) and records its
+    result dict."""
+    import json, tempfile, warnings
+    from types import SimpleNamespace as NS
+    zs = import_reference_tile_eval()
+    g = torch.Generator().manual_seed(seed)
+    D, C, N, R = 768, 4, 403, 260
+    names = ["Benign", "InSitu", "Invasive", "Normal"]
+    centers = torch.nn.functional.normalize(torch.randn(C, D, generator=g), dim=-1)
+    lab = torch.randint(0, C, (N,), generator=g)
+    img = centers[lab] * 1.3 + torch.randn(N, D, generator=g) * 0.1               # un-normalised image features
+    caps = {n: centers[c][None] * 0.6 + torch.randn(50, D, generator=g) * 0.11 for c, n in enumerate(names)}
+    prompts = {str(i): {"classnames": {n: f"{n.lower()} tissue v{i % 7}" for n in names}, "templates": f"a photo {i} of CLASSNAME."}
+               for i in range(50)}
+    ret_img = torch.randn(R, D, generator=g)
+    ret_txt = ret_img * 0.055 + torch.randn(R, D, generator=g)                     # p@10 / p@50 strictly inside (0, 1)
+    labels = [names[int(c)] for c in lab]
+
+    class Tok:                                   # BatchEncoding stand-in (not a dict: zero_shot.py:116 branches on that)
+        def __init__(self, texts):
+            self.texts = texts
+
+        def __getitem__(self, k):
+            return getattr(self, k)
+
+        def to(self, **kw):
+            return self
+
+    cap_lookup = {}
+    for n in names:
+        for i in range(50):
+            cap_lookup[prompts[str(i)]["templates"].replace("CLASSNAME", prompts[str(i)]["classnames"][n])] = caps[n][i]
+    txt_lookup = {f"caption {i}": ret_txt[i] for i in range(R)}
+
+    def bert_tok(texts, **kw):
+        return Tok(texts=list(texts))
+
+    class Model:
+        def eval(self):
+            return self
+
+        def encode_image(self, images):
+            return images                         # "images" are the pre-drawn features
+
+        def encode_text(self, inp):
+            return torch.stack([cap_lookup[t] for t in inp["texts"]])
+
+        def __call__(self, images, inp):
+            return {"image_features": images, "text_features": torch.stack([txt_lookup[t] for t in inp["texts"]])}
+
+    def loader(pairs, bs):
+        return NS(dataloader=[(torch.stack([p[0] for p in pairs[i:i + bs]]), [p[1] for p in pairs[i:i + bs]])
+                              for i in range(0, len(pairs), bs)])
+
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(prompts, f)
+    cfg = NS(SOLVER=NS(ZEROSHOT_FREQUENCY=1, EPOCHS=1), MODEL=NS(PRECISION="fp32", KNOWLEDGE_GUIDANCE=False, BERT_PRETRAIN="x",
+                                                                 TEXT_ENCODER="bert"),
+             DATASET=NS(ZEROSHOT_CLS_PROMPTS=f.name), DATALOADER=NS(BATCH_SIZE=64))
+    args = NS(distributed=False, horovod=False, device="cpu")
+    data = {"zeroshot_cls": loader(list(zip(img, labels)), 64),
+            "zeroshot_ret": loader([(ret_img[i], f"caption {i}") for i in range(R)], 32)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = zs.zero_shot_eval(Model(), {"bert": bert_tok}, data, 1, args, cfg)
+        ref_caps = zs.label2cap(cfg)
+    os.unlink(f.name)
+    # oracle agreement
+    assert O.label2cap(prompts) == ref_caps
+    val = O.tile_classification_rounds(img.numpy(), {n: caps[n].numpy() for n in names}, labels)
+    q = O.wf1_quartiles(val)
+    ret = O.retrieval_p_at_k(ret_img.numpy(), ret_txt.numpy())
+    for k in q:
+        assert abs(q[k] - res[k]) < 1e-12, (k, q[k], res[k])
+    assert ret["p@10"] == res["zeroshot-ret-p@10"] and ret["p@50"] == res["zeroshot-ret-p@50"]
+    print(f"[tile_eval] oracle == reference zero_shot_eval: {res}")
+    np.savez_compressed(os.path.join(GOLD, "tile_eval.npz"),
+                        img=img.numpy(), labels=np.array(labels), names=np.array(names),
+                        caps=np.stack([caps[n].numpy() for n in names]), prompts=json.dumps(prompts),
+                        ret_img=ret_img.numpy(), ret_txt=ret_txt.numpy(), wf1_rounds=val,
+                        wf1_median=res["zeroshot-cls-WF1-median"], wf1_q1=res["zeroshot-cls-WF1-Q1"], wf1_q3=res["zeroshot-cls-WF1-Q3"],
+                        p10=res["zeroshot-ret-p@10"], p50=res["zeroshot-ret-p@50"])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["wsi", "bert2", "bert12", "vit2", "vit24"]
+    which = sys.argv[1:] or ["wsi", "tile_eval", "bert2", "bert12", "vit2", "vit24"]
+    if "tile_eval" in which:
+        golden_tile_eval()
     if "wsi" in which:
         golden_wsi()
     if "bert2" in which:
