@@ -36,9 +36,9 @@ def main():
     ap.add_argument("--image", default=os.path.join(ROOT, "tests", "golden", "example.tif"))
     args = ap.parse_args()
     if args.model_path:
-        from transformers import AutoTokenizer
+        from keep_amd.tokenizer import load_tokenizer
         model = KEEPModel.from_pretrained(args.model_path)
-        tokenizer = AutoTokenizer.from_pretrained(args.model_path, do_lower_case=True, local_files_only=True)
+        tokenizer = load_tokenizer(args.model_path)
     else:
         from keep_amd.synth import synth_state_dict
         model = KEEPModel()

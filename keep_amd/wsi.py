@@ -136,6 +136,18 @@ def zero_shot_prompt_select(model, classifiers, tile_features, topn, device=None
     return torch.nn.functional.normalize(merge, p=2, dim=0)
 
 
+def random_prompt_ensemble(classifiers: Sequence[torch.Tensor], topn: int) -> torch.Tensor:
+    """The `prompt_screening = False` branch of the three scripts (zeroshot_subtyping_WSI.py:68-76): `topn` picks with
+    `random.seed(c); random.randint(0, K-1)` for c = 0..topn-1 (so the picks are the same on every run), summed and
+    column-normalised."""
+    import random
+    ensemble_cls = torch.zeros_like(classifiers[-1])
+    for cter in range(topn):
+        random.seed(cter)
+        ensemble_cls += classifiers[random.randint(0, len(classifiers) - 1)]
+    return torch.nn.functional.normalize(ensemble_cls, p=2, dim=0)
+
+
 # ------------------------------------------------------------------------------------------------
 def _probs(m: KEEPModel, classifier: torch.Tensor, tile_features: torch.Tensor) -> torch.Tensor:
     """softmax(10 * normalize(feat) @ classifier, dim=1) -- subtyping_utils.py:69-72."""

@@ -231,6 +231,18 @@ def zero_shot_prompt_select(classifiers: Sequence[Tensor], tile_features: Tensor
     return F.normalize(merged, p=2, dim=0)
 
 
+def random_prompt_ensemble(classifiers: Sequence[Tensor], topn: int) -> Tensor:
+    """zeroshot_subtyping_WSI.py:68-76 (same in the detection / segmentation scripts): unscreened ensemble."""
+    import random
+    acc = torch.zeros_like(classifiers[-1])
+    cter = 0
+    while cter < topn:
+        random.seed(cter)
+        acc = acc + classifiers[random.randint(0, len(classifiers) - 1)]
+        cter += 1
+    return F.normalize(acc, p=2, dim=0)
+
+
 def _dedupe_first(coords: np.ndarray) -> Tuple[Dict[Tuple[int, int], int], List[Tuple[int, int]]]:
     first: Dict[Tuple[int, int], int] = {}
     for i, c in enumerate(coords):
@@ -364,3 +376,56 @@ def retrieval_p_at_k(image_embeddings: np.ndarray, text_embeddings: np.ndarray) 
         p10 += int(t in best[:10])
         p50 += int(t in best[:50])
     return {"p@10": p10 / len(img), "p@50": p50 / len(img)}
+
+
+# --------------------------------------------------------------------------
+# BERT uncased WordPiece (third-party `tokenizers` / transformers BertTokenizer; published algorithm: BasicTokenizer
+# lower-casing + accent stripping + punctuation splitting, then greedy longest-match-first WordPiece with "##"
+# continuation pieces and [UNK] for words with no segmentation).  Pins the CALL the reference makes
+# (keep_inference.py:99, utils.py:73), not the PubMedBERT vocabulary, which is not available offline.
+# --------------------------------------------------------------------------
+def wordpiece_ids(vocab: Mapping[str, int], text: str, max_length: int = 256) -> Tuple[List[int], List[int]]:
+    import unicodedata
+
+    def is_punct(ch):
+        cp = ord(ch)
+        return (33 <= cp <= 47) or (58 <= cp <= 64) or (91 <= cp <= 96) or (123 <= cp <= 126) or unicodedata.category(ch).startswith("P")
+
+    text = unicodedata.normalize("NFD", text.lower())
+    text = "".join(c for c in text if unicodedata.category(c) != "Mn")
+    words: List[str] = []
+    for w in text.split():
+        cur = ""
+        for ch in w:
+            if is_punct(ch):
+                if cur:
+                    words.append(cur)
+                words.append(ch)
+                cur = ""
+            else:
+                cur += ch
+        if cur:
+            words.append(cur)
+    pieces: List[int] = []
+    for w in words:
+        start, sub = 0, []
+        while start < len(w):
+            end = len(w)
+            piece = None
+            while start < end:
+                cand = ("##" if start else "") + w[start:end]
+                if cand in vocab:
+                    piece = cand
+                    break
+                end -= 1
+            if piece is None:
+                sub = [vocab["[UNK]"]]
+                break
+            sub.append(vocab[piece])
+            start = end
+        pieces.extend(sub)
+    pieces = pieces[: max_length - 2]
+    ids = [vocab["[CLS]"]] + pieces + [vocab["[SEP]"]]
+    mask = [1] * len(ids) + [0] * (max_length - len(ids))
+    ids = ids + [vocab["[PAD]"]] * (max_length - len(ids))
+    return ids, mask
