@@ -75,6 +75,8 @@ struct keep_handle {
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
+    int lane_skew = 0;           // >0: lane l starts after lane l-1 finished stage `lane_skew` of block 0 (1 qkv .. 5 fc2)
+    hipEvent_t ev_skew[4] = {nullptr, nullptr, nullptr, nullptr};
     int lane0_permille = 500;    // share of a 2-lane chunk given to lane 0 (experiments with workgroup-round packing)
     int n_streams = 2;           // concurrent sub-batches inside keep_encode_image (1 = everything on the caller's stream)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -256,6 +258,7 @@ GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M
 // attention staging, GEMM epilogues, partial last rounds of workgroups) overlap the other lane's MFMA phases.
 struct VitLane {
     const void* pixels; int pix_dtype; int Bc; float* out; hipStream_t s; VitWs ws; bool cls_compact = false;
+    hipEvent_t skew_ev = nullptr; int skew_stage = 0;     // recorded after stage `skew_stage` of block 0 (lane_skew)
 };
 
 int vit_begin(keep_handle* h, VitLane& L) {
@@ -283,6 +286,7 @@ int vit_begin(keep_handle* h, VitLane& L) {
 int vit_layer(keep_handle* h, VitLane& L, int i) {
     const int D = h->vit_D, Bc = L.Bc, M = Bc * 197;
     hipStream_t s = L.s; VitWs& ws = L.ws;
+    auto mark = [&](int stage) { if (i == 0 && L.skew_ev && L.skew_stage == stage) (void)hipEventRecord(L.skew_ev, s); };
     {
         const VitBlock& b = h->vblocks[i];
         const bool sp = h->split_layer(i);
@@ -300,6 +304,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
             run_gemm(h, T_VIT_QKV, p, EPI_F16, s);
         }
+        mark(1);
         // Last block: everything after the attention is per-token and only the CLS token is pooled
         // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
         // Exact (same arithmetic on the rows that matter); the skipped FLOPs still count as algorithmic work.
@@ -312,6 +317,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             a.q_rows = cls_only ? 1 : 0;
             if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
         }
+        mark(2);
         const int Mr = cls_only ? Bc : M;
         float* resid = cls_only ? ws.c_resid : ws.resid;
         const f16 *att_hi = ws.att_hi, *att_lo = ws.att_lo;
@@ -330,6 +336,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             p.ls = b.ls1; p.resid = resid;
             run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s);
         }
+        mark(3);
         {
             Scope sc(h, T_VIT_LN, s);
             ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = sp ? xn_lo : nullptr;
@@ -342,12 +349,14 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             p.out_hi = mlp_hi; p.out_lo = sp ? mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
             run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s);
         }
+        mark(4);
         {
             Scope sc(h, T_VIT_FC2, s);
             GemmParams p = gemm_params(mlp_hi, mlp_lo, b.fc2, Mr, sp, b.fc2_b);
             p.ls = b.ls2; p.resid = resid;
             run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s);
         }
+        mark(5);
     }
     return KEEP_OK;
 }
@@ -740,6 +749,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
+    else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
     else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); g_ln_impl = v; }
     else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); g_attn_waves = v; }
@@ -831,8 +841,17 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
             x.s = lanes > 1 ? h->aux[l] : s;
             x.ws = carve_vit(h, h->arena + (size_t)l * lane_bytes, x.Bc, split);
         }
-        for (int l = 0; l < nl; ++l) if ((rc = vit_begin(h, L[l]))) return rc;
-        for (int i = 0; i < h->vit_depth; ++i)
+        const bool skew = nl > 1 && h->lane_skew > 0;
+        for (int l = 0; l < nl; ++l) {
+            if (skew) {
+                if (!h->ev_skew[l]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_skew[l], hipEventDisableTiming));
+                L[l].skew_ev = h->ev_skew[l]; L[l].skew_stage = h->lane_skew;
+                if (l > 0) HIPCHK(h, hipStreamWaitEvent(L[l].s, h->ev_skew[l - 1], 0));
+            }
+            if ((rc = vit_begin(h, L[l]))) return rc;
+            if (skew && (rc = vit_layer(h, L[l], 0))) return rc;
+        }
+        for (int i = skew ? 1 : 0; i < h->vit_depth; ++i)
             for (int l = 0; l < nl; ++l) if ((rc = vit_layer(h, L[l], i))) return rc;
         for (int l = 0; l < nl; ++l) if ((rc = vit_end(h, L[l]))) return rc;
     }
