@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkeep_hip.so")
+LIB_PATH = os.environ.get("KEEP_HIP_LIB") or os.path.join(_HERE, "libkeep_hip.so")     # override: A/B builds only
 
 KEEP_OK, KEEP_EINVAL, KEEP_ESTATE, KEEP_EKEY, KEEP_EHIP, KEEP_EUNSUPPORTED, KEEP_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 PIX_F32, PIX_F16, PIX_BF16, PIX_U8_HWC = 0, 1, 2, 3

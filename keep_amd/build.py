@@ -38,15 +38,24 @@ def up_to_date() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    # experiment builds: KEEP_BUILD_DEFINES="-DKEEP_A_AUX=2" KEEP_BUILD_OUT=libkeep_hip_x.so python -m keep_amd.build
+    # (loaded with KEEP_HIP_LIB=<path>, see _lib.py); the default build ignores both
+    defines = os.environ.get("KEEP_BUILD_DEFINES", "").split()
+    out = os.path.join(HERE, os.environ["KEEP_BUILD_OUT"]) if os.environ.get("KEEP_BUILD_OUT") else OUT
+    if defines or out != OUT:
+        return _build(out, os.path.join(HERE, "build_" + os.path.basename(out)), defines, verbose)
     if not force and up_to_date():
         return OUT
+    return _build(OUT, os.path.join(HERE, "build"), [], verbose)
+
+
+def _build(OUT: str, objdir: str, defines, verbose: bool) -> str:
     cc = hipcc()
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, *defines, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

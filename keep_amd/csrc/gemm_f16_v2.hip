@@ -18,6 +18,15 @@
 //   * nseg == 3: hi/lo split product through the same accumulators (strict precision)
 #include "gemm_epilogue.h"
 
+// Cache-policy bits of the two LDS-DMA streams (aux operand of global_load_lds: 2 = nt).  Tuning knobs for
+// tools/ab experiments (KEEP_BUILD_DEFINES); both default to the plain policy.
+#ifndef KEEP_A_AUX
+#define KEEP_A_AUX 0
+#endif
+#ifndef KEEP_W_AUX
+#define KEEP_W_AUX 0
+#endif
+
 namespace keepk {
 
 constexpr int V2_BM = 256, V2_BK = 32;
@@ -120,10 +129,10 @@ void gemm_f16_v2_kernel(GemmParams p) {
         f16* sw = sa + BM * BK;
 #pragma unroll
         for (int r = 0; r < A_ROUNDS; ++r)
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab + a_off[r]), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + a_off[r]), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
 #pragma unroll
         for (int r = 0; r < B_ROUNDS; ++r)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
     };
 
     f32x16 acc[TN][TM];
