@@ -16,7 +16,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkeep_hip.so")
-SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_v3.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
+SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_v3.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 
 

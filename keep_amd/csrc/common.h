@@ -83,12 +83,17 @@ struct GemmParams {
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
     int out_kt;                           // > 0: fp16 output in blk layout with KT = out_kt (= N/32); 0: row-major [M][N]
     int patches_per_img;                  // EPI_PATCH: 196
+    float* splitk_ws; size_t splitk_bytes; // scratch for the small-M split-K kernel (gemm_f16_skinny.hip); null: never used
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
     int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
 };
 
 void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);            // blk-layout operands (product path)
 void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s);   // row-major operands (test cross-check)
+// small-M split-K path: 30 MiB of scratch covers every shape with M <= SKINNY_MAX_M (<= 768 + 1024 partial tiles of 32 x 128 fp32)
+constexpr int SKINNY_MAX_M = 1024;
+constexpr size_t SKINNY_WS_BYTES = (size_t)(768 + 1024 + 64) * 32 * 128 * 4;
+int launch_gemm_f16_skinny(const GemmParams& p, int epi, float* ws, size_t ws_bytes, hipStream_t s);
 
 // Attention over a fused [M][3*D] qkv buffer (token-major; q|k|v, head-major inside each).
 struct AttnParams {

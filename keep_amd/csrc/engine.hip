@@ -22,6 +22,7 @@
 
 extern int g_attn_waves;
 extern int g_ln_impl;
+extern int g_gemm_skinny_m;
 extern int g_gemm_ablate;
 extern long long* g_gemm_dbg;
 extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
@@ -178,20 +179,21 @@ struct Carver {
     template <typename T> T* take(size_t n) { T* p = reinterpret_cast<T*>(base + off); off += align_up(n * sizeof(T)); return p; }
 };
 
-struct VitWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo, *pat_hi, *pat_lo; float *cls, *h1;
+struct VitWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo, *pat_hi, *pat_lo; float *cls, *h1;
                // compact CLS-row buffers for the last block
                float* c_resid; f16 *c_att_hi, *c_att_lo, *c_xn_hi, *c_xn_lo, *c_mlp_hi, *c_mlp_lo; };
-struct TxtWs { float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; };
+struct TxtWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; };
 
 size_t vit_ws_bytes(const keep_handle* h, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F, k = split ? 2 : 1;
-    return align_up(M * D * 4) + k * (align_up(blk_elems(M, D) * 2) * 2 + align_up(M * 3 * D * 2) + align_up(blk_elems(M, F) * 2)) + 2 * align_up(blk_elems(Mp, 768) * 2) +
+    return align_up(SKINNY_WS_BYTES) + align_up(M * D * 4) + k * (align_up(blk_elems(M, D) * 2) * 2 + align_up(M * 3 * D * 2) + align_up(blk_elems(M, F) * 2)) + 2 * align_up(blk_elems(Mp, 768) * 2) +
            align_up((size_t)Bc * D * 4) + align_up((size_t)Bc * h->proj_dim * 4) + 4096 +
            align_up((size_t)Bc * D * 4) + 2 * (2 * align_up(blk_elems(Bc, D) * 2) + align_up(blk_elems(Bc, F) * 2));
 }
 VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F;
     Carver c(arena); VitWs w{};
+    w.splitk = c.take<float>(SKINNY_WS_BYTES / 4);
     w.resid = c.take<float>(M * D);
     w.xn_hi = c.take<f16>(blk_elems(M, D));  w.xn_lo = split ? c.take<f16>(blk_elems(M, D)) : nullptr;
     w.qkv_hi = c.take<f16>(M * 3 * D);       w.qkv_lo = split ? c.take<f16>(M * 3 * D) : nullptr;
@@ -208,11 +210,12 @@ VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
 }
 size_t txt_ws_bytes(const keep_handle* h, int64_t Pc, int64_t T, bool split) {
     const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F, k = split ? 2 : 1;
-    return align_up(M * H * 4) + k * (align_up(blk_elems(M, H) * 2) * 2 + align_up(M * 3 * H * 2) + align_up(blk_elems(M, F) * 2)) + 4096;
+    return align_up(SKINNY_WS_BYTES) + align_up(M * H * 4) + k * (align_up(blk_elems(M, H) * 2) * 2 + align_up(M * 3 * H * 2) + align_up(blk_elems(M, F) * 2)) + 4096;
 }
 TxtWs carve_txt(const keep_handle* h, char* arena, int64_t Pc, int64_t T, bool split) {
     const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F;
     Carver c(arena); TxtWs w{};
+    w.splitk = c.take<float>(SKINNY_WS_BYTES / 4);
     w.resid = c.take<float>(M * H);
     w.xn_hi = c.take<f16>(blk_elems(M, H));  w.xn_lo = split ? c.take<f16>(blk_elems(M, H)) : nullptr;
     w.qkv_hi = c.take<f16>(M * 3 * H);       w.qkv_lo = split ? c.take<f16>(M * 3 * H) : nullptr;
@@ -237,8 +240,9 @@ int check_launch(keep_handle* h, const char* what) {
     return KEEP_OK;
 }
 
-void run_gemm(keep_handle* h, int tag, const GemmParams& p, int epi, hipStream_t s) {
+void run_gemm(keep_handle* h, int tag, GemmParams p, int epi, hipStream_t s, float* splitk) {
     h->prof_add_flops(tag, 2.0 * p.M * (double)p.N * p.K * p.nseg);
+    p.splitk_ws = splitk; p.splitk_bytes = SKINNY_WS_BYTES;
     launch_gemm_f16(p, epi, s);
 }
 
@@ -278,7 +282,7 @@ int vit_begin(keep_handle* h, VitLane& L) {
                                    find(h, "visual.patch_embed.proj.bias")->f32);
         p.pos = find(h, "visual.pos_embed")->f32;
         p.resid = ws.resid;
-        run_gemm(h, T_VIT_PATCH, p, EPI_PATCH, s);
+        run_gemm(h, T_VIT_PATCH, p, EPI_PATCH, s, ws.splitk);
     }
     return KEEP_OK;
 }
@@ -302,7 +306,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_QKV, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-            run_gemm(h, T_VIT_QKV, p, EPI_F16, s);
+            run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk);
         }
         mark(1);
         // Last block: everything after the attention is per-token and only the CLS token is pooled
@@ -334,7 +338,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_PROJ, s);
             GemmParams p = gemm_params(att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
             p.ls = b.ls1; p.resid = resid;
-            run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s);
+            run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
         }
         mark(3);
         {
@@ -347,14 +351,14 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_FC1, s);
             GemmParams p = gemm_params(xn_hi, xn_lo, b.fc1, Mr, sp, b.fc1_b);
             p.out_hi = mlp_hi; p.out_lo = sp ? mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
-            run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s);
+            run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s, ws.splitk);
         }
         mark(4);
         {
             Scope sc(h, T_VIT_FC2, s);
             GemmParams p = gemm_params(mlp_hi, mlp_lo, b.fc2, Mr, sp, b.fc2_b);
             p.ls = b.ls2; p.resid = resid;
-            run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s);
+            run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk);
         }
         mark(5);
     }
@@ -409,7 +413,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_QKV, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-            run_gemm(h, T_TXT_QKV, p, EPI_F16, s);
+            run_gemm(h, T_TXT_QKV, p, EPI_F16, s, ws.splitk);
         }
         {
             Scope sc(h, T_TXT_ATTN, s);
@@ -423,7 +427,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_OUT, s);
             GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.o, M, sp, b.o_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
-            run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s);
+            run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s, ws.splitk);
         }
         LnParams ln{};
         ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
@@ -437,13 +441,13 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_FFN1, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
             p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->bert_F / 32;
-            run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s);
+            run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s, ws.splitk);
         }
         {
             Scope sc(h, T_TXT_FFN2, s);
             GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.d, M, sp, b.d_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
-            run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s);
+            run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s, ws.splitk);
         }
         {
             Scope sc(h, T_TXT_LN, s);
@@ -749,6 +753,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
+    else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); g_gemm_skinny_m = v; }
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
     else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); g_ln_impl = v; }
@@ -771,6 +776,12 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "max_prompts") return h->max_prompts;
     if (n == "gemm_impl") return g_gemm_impl;
     if (n == "streams") return h->n_streams;
+    if (n == "gemm_skinny_m") return g_gemm_skinny_m;
+    if (n == "ln_impl") return g_ln_impl;
+    if (n == "attn_waves") return g_attn_waves;
+    if (n == "lane_skew") return h->lane_skew;
+    if (n == "lane0_permille") return h->lane0_permille;
+    if (n == "cls_tail") return h->cls_tail;
     return -1;
 }
 
@@ -1078,6 +1089,10 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     GemmParams p{};
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.nseg = split ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
+    if (!rowmajor && M <= SKINNY_MAX_M) {          // auto mode sends small M to the split-K kernel, as the towers do
+        p.splitk_ws = t.get<float>(SKINNY_WS_BYTES / 4); p.splitk_bytes = SKINNY_WS_BYTES;
+        if (!p.splitk_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
+    }
     auto launch = [&](const GemmParams& q) { if (rowmajor) launch_gemm_f16_rowmajor(q, epi, s); else launch_gemm_f16(q, epi, s); };
     if (epi == EPI_F16 || epi == EPI_GELU_F16) {
         p.out_hi = o_hi; p.out_lo = split ? o_lo : nullptr;

@@ -146,6 +146,8 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
 int launch_gemm_f16_v3(const GemmParams& p, int epi, hipStream_t s);
 int g_gemm_ablate = 0;
 long long* g_gemm_dbg = nullptr;
+int g_gemm_skinny_m = 1024;  // calls with M <= this many rows take the split-K kernel (0: never).  Measured crossover
+                             // against the 256x256 kernel: M = 788 (4 tiles) 3.7 vs 4.6 ms per encode_image, M = 1576 5.6 vs 4.6
 int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
 
 void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
@@ -154,6 +156,8 @@ void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     p.ablate = g_gemm_ablate;
     p.dbg = g_gemm_dbg;
     int impl = g_gemm_impl;
+    if (impl == 0 && p.M <= g_gemm_skinny_m && p.M <= SKINNY_MAX_M && p.splitk_ws &&
+        launch_gemm_f16_skinny(p, epi, p.splitk_ws, p.splitk_bytes, s) == 0) return;
     if (impl == 3 && launch_gemm_f16_v3(p, epi, s) == 0) return;       // persistent 256x256 variant
     if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256) || ((impl == 256 || impl == 3256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
     launch_gemm_f16_v2(p, epi, impl, s);

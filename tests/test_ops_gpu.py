@@ -27,12 +27,17 @@ GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 40
                (2048, 1024, 1024), (1000, 256, 192)]
 
 
-@pytest.fixture(params=[1, 128, 256, 2128, 3], ids=["v1_128x128", "v2_256x128", "v2_256x256", "v2_256x128_2wg", "v3_persistent"])
+@pytest.fixture(params=[1, 128, 256, 2128, 3, 0], ids=["v1_128x128", "v2_256x128", "v2_256x256", "v2_256x128_2wg", "v3_persistent", "auto_splitk"])
 def gemm_impl(ops, request):
-    """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile)."""
+    """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile).  0 = the
+    product's automatic choice, with the small-M split-K kernel taking every shape up to its 1024-row limit."""
     ops.set_option("gemm_impl", request.param)
+    skinny = 1024
+    if request.param == 0:
+        ops.set_option("gemm_skinny_m", 1024)
     yield request.param
     ops.set_option("gemm_impl", 0)
+    ops.set_option("gemm_skinny_m", skinny)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
