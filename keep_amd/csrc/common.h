@@ -83,12 +83,17 @@ struct GemmParams {
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
     int out_kt;                           // > 0: fp16 output in blk layout with KT = out_kt (= N/32); 0: row-major [M][N]
     int patches_per_img;                  // EPI_PATCH: 196
+    // optional LayerNorm of the updated row, fused into the split-K reduce (EPI_RESID_LS / EPI_RESID_F32, N <= 1024);
+    // launch_gemm_f16 reports through its return value whether it was applied (bit 0) -- the big kernel never does
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    f16* ln_out_hi; f16* ln_out_lo; float* ln_out_f32;   // fp16 in blk layout (KT = N / 32); fp32 row-major [M][N], may alias resid / out_f32
     float* splitk_ws; size_t splitk_bytes; // scratch for the small-M split-K kernel (gemm_f16_skinny.hip); null: never used
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
     int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
 };
 
-void launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);            // blk-layout operands (product path)
+int launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);             // blk-layout operands (product path); returns GEMM_DID_LN or 0
+constexpr int GEMM_DID_LN = 1;
 void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s);   // row-major operands (test cross-check)
 // small-M split-K path: 30 MiB of scratch covers every shape with M <= SKINNY_MAX_M (<= 768 + 1024 partial tiles of 32 x 128 fp32)
 constexpr int SKINNY_MAX_M = 1024;

@@ -23,6 +23,7 @@
 extern int g_attn_waves;
 extern int g_ln_impl;
 extern int g_gemm_skinny_m;
+extern int g_sgemv_m;
 extern int g_gemm_ablate;
 extern long long* g_gemm_dbg;
 extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
@@ -240,10 +241,16 @@ int check_launch(keep_handle* h, const char* what) {
     return KEEP_OK;
 }
 
-void run_gemm(keep_handle* h, int tag, GemmParams p, int epi, hipStream_t s, float* splitk) {
+int run_gemm(keep_handle* h, int tag, GemmParams p, int epi, hipStream_t s, float* splitk) {
     h->prof_add_flops(tag, 2.0 * p.M * (double)p.N * p.K * p.nseg);
     p.splitk_ws = splitk; p.splitk_bytes = SKINNY_WS_BYTES;
-    launch_gemm_f16(p, epi, s);
+    return launch_gemm_f16(p, epi, s);
+}
+
+// offer the LayerNorm that follows a residual GEMM to the GEMM itself (taken only on the small-M split-K path)
+void offer_ln(GemmParams& p, const LnParams& ln) {
+    p.ln_gamma = ln.gamma; p.ln_beta = ln.beta; p.ln_eps = ln.eps;
+    p.ln_out_hi = ln.out_hi; p.ln_out_lo = ln.out_lo; p.ln_out_f32 = ln.out_f32;
 }
 
 GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M, bool split, const float* bias) {
@@ -263,6 +270,7 @@ GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M
 struct VitLane {
     const void* pixels; int pix_dtype; int Bc; float* out; hipStream_t s; VitWs ws; bool cls_compact = false;
     hipEvent_t skew_ev = nullptr; int skew_stage = 0;     // recorded after stage `skew_stage` of block 0 (lane_skew)
+    bool xn_ready = false;                                // the previous block's fc2 already wrote this block's LayerNorm-1 output
 };
 
 int vit_begin(keep_handle* h, VitLane& L) {
@@ -297,11 +305,12 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         LnParams ln{};
         ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
         ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr; ln.out_kt = D / 32;
-        {
+        if (!L.xn_ready) {
             Scope sc(h, T_VIT_LN, s);
             ln.gamma = b.n1w; ln.beta = b.n1b;
             if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
         }
+        L.xn_ready = false;
         {
             Scope sc(h, T_VIT_QKV, s);
             GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
@@ -334,17 +343,19 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             att_hi = ws.c_att_hi; att_lo = ws.c_att_lo; xn_hi = ws.c_xn_hi; xn_lo = ws.c_xn_lo; mlp_hi = ws.c_mlp_hi; mlp_lo = ws.c_mlp_lo;
             L.cls_compact = true;
         }
+        ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = sp ? xn_lo : nullptr;
+        ln.gamma = b.n2w; ln.beta = b.n2b;
+        int did;
         {
             Scope sc(h, T_VIT_PROJ, s);
             GemmParams p = gemm_params(att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
             p.ls = b.ls1; p.resid = resid;
-            run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
+            offer_ln(p, ln);
+            did = run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
         }
         mark(3);
-        {
+        if (!(did & GEMM_DID_LN)) {
             Scope sc(h, T_VIT_LN, s);
-            ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = sp ? xn_lo : nullptr;
-            ln.gamma = b.n2w; ln.beta = b.n2b;
             launch_layernorm(ln, s);
         }
         {
@@ -358,7 +369,13 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             Scope sc(h, T_VIT_FC2, s);
             GemmParams p = gemm_params(mlp_hi, mlp_lo, b.fc2, Mr, sp, b.fc2_b);
             p.ls = b.ls2; p.resid = resid;
-            run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk);
+            if (i + 1 < h->vit_depth && !cls_only) {        // next block's LayerNorm-1 reads exactly the rows written here
+                const VitBlock& nb = h->vblocks[i + 1];
+                ln.x = ws.resid; ln.rows = M; ln.out_hi = ws.xn_hi; ln.out_lo = h->split_layer(i + 1) ? ws.xn_lo : nullptr;
+                ln.gamma = nb.n1w; ln.beta = nb.n1b;
+                offer_ln(p, ln);
+            }
+            L.xn_ready = (run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk) & GEMM_DID_LN) != 0;
         }
         mark(5);
     }
@@ -423,18 +440,20 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %d unsupported%s", T,
                                                        sp ? " in strict mode (max 256)" : " (max 512)");
         }
+        LnParams ln{};
+        ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
+        ln.out_f32 = ws.resid; ln.out_f32_stride = H; ln.out_hi = ws.xn_hi; ln.out_kt = H / 32;
+        ln.gamma = b.ln1w; ln.beta = b.ln1b; ln.out_lo = sp ? ws.xn_lo : nullptr;
+        int did;
         {
             Scope sc(h, T_TXT_OUT, s);
             GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.o, M, sp, b.o_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
-            run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s, ws.splitk);
+            offer_ln(p, ln);
+            did = run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s, ws.splitk);
         }
-        LnParams ln{};
-        ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
-        ln.out_f32 = ws.resid; ln.out_f32_stride = H; ln.out_hi = ws.xn_hi; ln.out_kt = H / 32;
-        {
+        if (!(did & GEMM_DID_LN)) {
             Scope sc(h, T_TXT_LN, s);
-            ln.gamma = b.ln1w; ln.beta = b.ln1b; ln.out_lo = sp ? ws.xn_lo : nullptr;
             if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", H);
         }
         {
@@ -443,15 +462,16 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->bert_F / 32;
             run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s, ws.splitk);
         }
+        ln.gamma = b.ln2w; ln.beta = b.ln2b; ln.out_lo = sp_next ? ws.xn_lo : nullptr;
         {
             Scope sc(h, T_TXT_FFN2, s);
             GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.d, M, sp, b.d_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
-            run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s, ws.splitk);
+            offer_ln(p, ln);
+            did = run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s, ws.splitk);
         }
-        {
+        if (!(did & GEMM_DID_LN)) {
             Scope sc(h, T_TXT_LN, s);
-            ln.gamma = b.ln2w; ln.beta = b.ln2b; ln.out_lo = sp_next ? ws.xn_lo : nullptr;
             launch_layernorm(ln, s);
         }
     }
@@ -753,6 +773,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
+    else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); g_sgemv_m = v; }
     else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); g_gemm_skinny_m = v; }
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
@@ -777,6 +798,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "gemm_impl") return g_gemm_impl;
     if (n == "streams") return h->n_streams;
     if (n == "gemm_skinny_m") return g_gemm_skinny_m;
+    if (n == "sgemv_m") return g_sgemv_m;
     if (n == "ln_impl") return g_ln_impl;
     if (n == "attn_waves") return g_attn_waves;
     if (n == "lane_skew") return h->lane_skew;

@@ -150,17 +150,20 @@ int g_gemm_skinny_m = 1024;  // calls with M <= this many rows take the split-K 
                              // against the 256x256 kernel: M = 788 (4 tiles) 3.7 vs 4.6 ms per encode_image, M = 1576 5.6 vs 4.6
 int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
 
-void launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
+int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     // Operands in blk layout -> the LDS-DMA kernels (gemm_f16_v2.hip); g_gemm_impl only picks the tile width.
     GemmParams p = p_in;
     p.ablate = g_gemm_ablate;
     p.dbg = g_gemm_dbg;
     int impl = g_gemm_impl;
-    if (impl == 0 && p.M <= g_gemm_skinny_m && p.M <= SKINNY_MAX_M && p.splitk_ws &&
-        launch_gemm_f16_skinny(p, epi, p.splitk_ws, p.splitk_bytes, s) == 0) return;
-    if (impl == 3 && launch_gemm_f16_v3(p, epi, s) == 0) return;       // persistent 256x256 variant
+    if (impl == 0 && p.M <= g_gemm_skinny_m && p.M <= SKINNY_MAX_M && p.splitk_ws) {
+        const int rc = launch_gemm_f16_skinny(p, epi, p.splitk_ws, p.splitk_bytes, s);
+        if (rc >= 0) return rc;
+    }
+    if (impl == 3 && launch_gemm_f16_v3(p, epi, s) == 0) return 0;     // persistent 256x256 variant
     if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256) || ((impl == 256 || impl == 3256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
     launch_gemm_f16_v2(p, epi, impl, s);
+    return 0;
 }
 
 // Row-major operands: the register-staged 128x128 kernel above (cross-check variant for the op tests).

@@ -123,6 +123,66 @@ void gemm_skinny_reduce_kernel(GemmParams p, const float* __restrict__ part, int
     }
 }
 
+// Same sum + residual epilogue for a WHOLE output row per workgroup (N <= 1024: one thread per 4 columns), followed by
+// the LayerNorm that consumes the row next (two-pass statistics over the row held in registers): saves the
+// LayerNorm launch and its read of the row on the latency path.
+template <int EPI>
+__global__ __launch_bounds__(256)
+void gemm_skinny_reduce_ln_kernel(GemmParams p, const float* __restrict__ part, int S) {
+    __shared__ float red[2][4];
+    const int m = blockIdx.x, t = threadIdx.x, n = t * 4;
+    const bool on = n < p.N;
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)m * p.N + n);
+        for (int s = 1; s < S; ++s) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(part + ((int64_t)s * p.M + m) * p.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += x[e];
+        }
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+        const int64_t o = (int64_t)m * p.N + n;
+        r = *reinterpret_cast<const f32x4*>(p.resid + o);
+        if (EPI == EPI_RESID_LS) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] += g[e] * (v[e] + bias[e]);
+            *reinterpret_cast<f32x4*>(p.resid + o) = r;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (v[e] + bias[e]) + r[e];
+            if (p.ln_out_f32 != p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + o) = r;
+        }
+    }
+    const int wave = t >> 6, lane = t & 63;
+    float sum = wave_sum(r[0] + r[1] + r[2] + r[3]);
+    if (lane == 0) red[0][wave] = sum;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)p.N;
+    float sq = 0.f;
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] -= mean; sq += r[e] * r[e]; }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[1][wave] = sq;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)p.N + p.ln_eps);
+    if (!on) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + n);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_beta + n);
+    f32x4 y; f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        y[e] = r[e] * rstd * g[e] + bt[e];
+        f16 hh, ll; split_f16(y[e], hh, ll); h[e] = hh; l[e] = ll;
+    }
+    if (p.ln_out_f32) *reinterpret_cast<f32x4*>(p.ln_out_f32 + (int64_t)m * p.N + n) = y;
+    const int64_t oo = blk_off(m, n, p.N / 32);
+    *reinterpret_cast<f16x4*>(p.ln_out_hi + oo) = h;
+    if (p.ln_out_lo) *reinterpret_cast<f16x4*>(p.ln_out_lo + oo) = l;
+}
+
 }  // namespace keepk
 using namespace keepk;
 
@@ -136,7 +196,7 @@ int skinny_splits(int M, int N, int K) {
 
 size_t skinny_ws_bytes(int M, int N, int K) { return (size_t)skinny_splits(M, N, K) * M * N * sizeof(float); }
 
-// Returns 0 when launched, -1 when the shape is not eligible (caller falls back to the big kernel).
+// Returns -1 when the shape is not eligible (caller falls back to the big kernel), else 0 or GEMM_DID_LN.
 int launch_gemm_f16_skinny(const GemmParams& p, int epi, float* ws, size_t ws_bytes, hipStream_t s) {
     if (!ws || p.N % SK_BN || p.K % 32 || p.M < 1) return -1;
     const int S = skinny_splits(p.M, p.N, p.K);
@@ -144,6 +204,11 @@ int launch_gemm_f16_skinny(const GemmParams& p, int epi, float* ws, size_t ws_by
     const int KT = p.K / 32, per = (KT + S - 1) / S;
     dim3 grid(p.N / SK_BN, (p.M + SK_BM - 1) / SK_BM, S), block(256);
     hipLaunchKernelGGL(gemm_skinny_partial_kernel, grid, block, 0, s, p, ws, per);
+    if (p.ln_gamma && p.ln_out_hi && (epi == EPI_RESID_LS || epi == EPI_RESID_F32) && p.N <= 1024) {
+        if (epi == EPI_RESID_LS) hipLaunchKernelGGL(gemm_skinny_reduce_ln_kernel<EPI_RESID_LS>, dim3(p.M), block, 0, s, p, ws, S);
+        else hipLaunchKernelGGL(gemm_skinny_reduce_ln_kernel<EPI_RESID_F32>, dim3(p.M), block, 0, s, p, ws, S);
+        return GEMM_DID_LN;
+    }
     const int64_t items = (int64_t)p.M * (p.N / 4);
     dim3 rg((unsigned)((items + 255) / 256));
     switch (epi) {

@@ -90,11 +90,54 @@ void sgemm_f32_nt_kernel(SgemmParams p) {
         }
 }
 
+// Few-row variant (M <= 16: one tile's projection head, one prompt's pooler).  The MFMA kernel above gives such a call
+// N/128 workgroups that each walk K alone (76 us for the pooler of one prompt); here one wave owns one output column,
+// keeps that B row in registers and reduces across lanes -- N waves, ~3 us.  fp32 FMA throughout.
+constexpr int GEMV_MAX_M = 16, GEMV_MAX_K = 1024;
+__global__ __launch_bounds__(256)
+void sgemv_f32_nt_kernel(SgemmParams p) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    constexpr int KV = GEMV_MAX_K / 256;             // float4 per lane
+    f32x4 b[KV];
+    const float* brow = p.b + (int64_t)n * p.ldb;
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        b[i] = k < p.K ? *reinterpret_cast<const f32x4*>(brow + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int m = 0; m < p.M; ++m) {
+        const float* arow = p.a + (int64_t)m * p.lda;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            const int k = (i * 64 + lane) * 4;
+            if (k < p.K) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(arow + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fmaf(a[e], b[i][e], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = acc * p.scale + (p.bias ? p.bias[n] : 0.f);
+            if (p.act == ACT_GELU) v = gelu_erf(v);
+            else if (p.act == ACT_TANH) v = tanhf(v);
+            p.out[(int64_t)m * p.ldo + n] = v;
+        }
+    }
+}
+
 }  // namespace keepk
 
+int g_sgemv_m = keepk::GEMV_MAX_M;      // rows up to which the few-row kernel is used (0: never)
 int launch_sgemm_f32(const SgemmParams& p, hipStream_t s) {
     if (p.K % keepk::SK != 0 || p.M < 1 || p.N < 1) return -1;
     if ((p.lda % 4) || (p.ldb % 4)) return -1;
+    if (p.M <= g_sgemv_m && p.K <= keepk::GEMV_MAX_K && p.K % 4 == 0) {
+        hipLaunchKernelGGL(keepk::sgemv_f32_nt_kernel, dim3((p.N + 3) / 4), dim3(256), 0, s, p);
+        return 0;
+    }
     dim3 grid((p.N + keepk::SB - 1) / keepk::SB, (p.M + keepk::SB - 1) / keepk::SB);
     hipLaunchKernelGGL(keepk::sgemm_f32_nt_kernel, grid, dim3(256), 0, s, p);
     return 0;

@@ -188,8 +188,10 @@ def no_splitk():
     from keep_amd.ops import Ops
     o = Ops()
     o.set_option("gemm_skinny_m", 0)
+    o.set_option("sgemv_m", 0)             # likewise the few-row fp32 kernel of the head / pooler
     yield
     o.set_option("gemm_skinny_m", 1024)
+    o.set_option("sgemv_m", 16)
 
 
 def test_splitk_path_matches_big_kernel(small, text_bank):
@@ -202,11 +204,11 @@ def test_splitk_path_matches_big_kernel(small, text_bank):
         m = make_model(small, precision)
         a_img, a_txt = m.encode_image(x), m.encode_text(toks)
         assert torch.equal(m.encode_image(x), a_img) and torch.equal(m.encode_text(toks), a_txt)
-        o.set_option("gemm_skinny_m", 0)
+        o.set_option("gemm_skinny_m", 0); o.set_option("sgemv_m", 0)
         try:
             b_img, b_txt = m.encode_image(x), m.encode_text(toks)
         finally:
-            o.set_option("gemm_skinny_m", 1024)
+            o.set_option("gemm_skinny_m", 1024); o.set_option("sgemv_m", 16)
         d = max((a_img - b_img).abs().max().item(), (a_txt - b_txt).abs().max().item())
         print(f"[splitk vs 256x256 {precision}] max|dfeat|={d:.3e}")
         assert d < tol
