@@ -89,8 +89,15 @@ int keep_bert_layers(keep_handle* h);
  *                     back onto the caller's stream with events (no host synchronisation)
  *   "cls_tail"        1 (default): in the last ViT block run proj / MLP for the CLS rows only (exact: the
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
- *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256: 256xBN LDS-DMA variant
- *                     (process-wide kernel selection override, for tests and A/B measurements)
+ *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256 / 2128 / 3256: LDS-DMA tile variants |
+ *                     3 persistent (process-wide kernel selection override, for tests and A/B measurements)
+ *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 1024, 0 never;
+ *                     process-wide).  The two GEMM paths agree to rounding, each is bit-reproducible
+ *   "sgemv_m"         same for the few-row fp32 kernel of the projection head / pooler / similarity (default 16)
+ *   "ln_impl"         1 (default) LayerNorm with LDS-transposed K-blocked stores | 0 per-row stores
+ *   "attn_waves"      wavefronts per attention workgroup, 8 (default) | 4
+ *   "lane0_permille", "lane_skew"   experiments with the two-lane schedule (defaults 500 / 0 measured best)
+ *   "gemm_ablate", "gemm_dbg"       diagnostics for tools/gemm_timeline.py (results are wrong when ablating)
  */
 int keep_set_option(keep_handle* h, const char* name, double value);
 double keep_get_option(keep_handle* h, const char* name);
