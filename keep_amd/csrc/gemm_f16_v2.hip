@@ -70,10 +70,11 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // tile coordinates: consecutive workgroups share the A panel (same m tile, different n tile)
     // XCD-aware, L2-blocked tile order.  Hardware places workgroup b on XCD b % 8 (used for speed only,
     // never for correctness).  Each XCD gets a contiguous run of the tile sequence (bijective for any
-    // grid size), and the sequence itself walks the tile grid in column bands of 4 n-tiles, m fastest
-    // after n: the ~32 workgroups resident on one XCD then cover an ~8 x 4 patch of tiles (each A
-    // panel shared by 4 CUs, each W panel by 8) and the band's W panels stay in that XCD's 4 MiB L2
-    // from one round to the next.  (Band width 8: the patch becomes ~4 x 8.)
+    // grid size), and the sequence walks the tile grid in column bands of BW n-tiles, n fastest, then m:
+    // the ~32 workgroups resident on one XCD cover a ~4 x 8 patch of tiles, so per K step that XCD's L2
+    // fetches 4 A slices + 8 W slices for 64 slice reads (measured LDS-DMA hit rate 79 %).  A band's W
+    // (4 MB at K = 1024) does not survive in the 4 MiB L2 from one round to the next; it comes back from
+    // the Infinity Cache (profiles/README.md).
     const int ntn = p.N / BN;
     const int mtn = (p.M + BM - 1) / BM;
     const int nwg = gridDim.x;
