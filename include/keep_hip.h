@@ -91,6 +91,8 @@ int keep_bert_layers(keep_handle* h);
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
  *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256 / 2128 / 3256: LDS-DMA tile variants |
  *                     3 persistent (process-wide kernel selection override, for tests and A/B measurements)
+ *   "graphs"          1 (default): calls of at most 1024 rows (a few prompts / tiles: ~100 dependent kernels of a few
+ *                     microseconds) are captured once and replayed as one hipGraph launch; 0: always launch kernels
  *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 1024, 0 never;
  *                     process-wide).  The two GEMM paths agree to rounding, each is bit-reproducible
  *   "sgemv_m"         same for the few-row fp32 kernel of the projection head / pooler / similarity (default 16)

@@ -77,6 +77,11 @@ struct keep_handle {
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
+    // hipGraph replay of launch-bound calls (one prompt / one tile: ~100 dependent kernels of a few us each)
+    struct GraphSlot { hipGraphExec_t exec; unsigned long long epoch; char* arena; };
+    std::map<std::string, GraphSlot> graphs;
+    int use_graphs = 1;
+    hipStream_t cap_stream = nullptr;
     int dbg_calls = 0;
     int dbg_skip_ln = 0;         // diagnostics (takes effect from the 4th encode_image call, so the buffers hold real data): skip the ViT block LayerNorm launches (results wrong; bounds what fusing them away could gain)
     int lane_skew = 0;           // >0: lane l starts after lane l-1 finished stage `lane_skew` of block 0 (1 qkv .. 5 fc2)
@@ -240,6 +245,43 @@ int ensure_arena(keep_handle* h, size_t bytes) {
 int check_launch(keep_handle* h, const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return h->fail(KEEP_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return KEEP_OK;
+}
+
+// Bumped by every keep_set_option / keep_finalize_weights (kernel selection is partly process-wide): graphs captured
+// under an older epoch, or against an arena that has since been reallocated, are dropped and captured again.
+unsigned long long g_opt_epoch = 0;
+
+void drop_graphs(keep_handle* h) {
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+}
+
+// Replays `body` (which must only enqueue work on the stream it is given: no allocation, no synchronisation) as one
+// graph launch on `s`; captures it on first use.
+template <class F>
+int graph_run(keep_handle* h, const std::string& key, hipStream_t s, F&& body) {
+    auto it = h->graphs.find(key);
+    if (it != h->graphs.end() && (it->second.epoch != g_opt_epoch || it->second.arena != h->arena)) {
+        (void)hipGraphExecDestroy(it->second.exec);
+        h->graphs.erase(it);
+        it = h->graphs.end();
+    }
+    if (it == h->graphs.end()) {
+        if (!h->cap_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = body(h->cap_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        HIPCHK(h, e);
+        hipGraphExec_t ex = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        HIPCHK(h, ei);
+        it = h->graphs.emplace(key, keep_handle::GraphSlot{ex, g_opt_epoch, h->arena}).first;
+    }
+    HIPCHK(h, hipGraphLaunch(it->second.exec, s));
     return KEEP_OK;
 }
 
@@ -720,6 +762,8 @@ int keep_destroy(keep_handle* h) {
     for (auto& e : h->pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo); }
     for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
+    drop_graphs(h);
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     if (h->arena) hipFree(h->arena);
     if (h->err_flag) hipFree(h->err_flag);
     for (int l = 0; l < 4; ++l) { if (h->aux[l]) hipStreamDestroy(h->aux[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
@@ -752,6 +796,7 @@ int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndi
 int keep_finalize_weights(keep_handle* h) {
     if (!h) return KEEP_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    ++g_opt_epoch;
     int rc = finalize_vit(h);
     if (rc) return rc;
     rc = finalize_bert(h);
@@ -769,6 +814,8 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     if (!h || !name) return KEEP_EINVAL;
     const std::string n(name);
     const int v = (int)value;
+    ++g_opt_epoch;
+    if (n == "graphs") { h->use_graphs = v ? 1 : 0; return KEEP_OK; }
     if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
@@ -800,6 +847,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "max_prompts") return h->max_prompts;
     if (n == "gemm_impl") return g_gemm_impl;
     if (n == "streams") return h->n_streams;
+    if (n == "graphs") return h->use_graphs;
     if (n == "gemm_skinny_m") return g_gemm_skinny_m;
     if (n == "sgemv_m") return g_sgemv_m;
     if (n == "ln_impl") return g_ln_impl;
@@ -839,6 +887,29 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     ++h->dbg_calls;
+    if (h->use_graphs && !h->prof_mode && B * 197 <= SKINNY_MAX_M && B <= h->max_tiles) {
+        const size_t pxb = pix_dtype == KEEP_PIX_F32 ? 4 : (pix_dtype == KEEP_PIX_U8_HWC ? 1 : 2);
+        const bool sp = h->any_split();
+        const size_t ws_bytes = align_up(vit_ws_bytes(h, B, sp)), ib = (size_t)B * 3 * 224 * 224 * pxb, ob = (size_t)B * h->proj_dim * sizeof(float);
+        int rc = ensure_arena(h, ws_bytes + align_up(ib) + align_up(ob));
+        if (rc) return rc;
+        char* st_pix = h->arena + ws_bytes;
+        float* st_out = (float*)(h->arena + ws_bytes + align_up(ib));
+        HIPCHK(h, hipMemcpyAsync(st_pix, pixels, ib, hipMemcpyDeviceToDevice, s));
+        char key[96];
+        snprintf(key, sizeof key, "img|%lld|%d", (long long)B, pix_dtype);
+        rc = graph_run(h, key, s, [&](hipStream_t cs) {
+            VitLane L{};
+            L.Bc = (int)B; L.pixels = st_pix; L.pix_dtype = pix_dtype; L.out = st_out; L.s = cs;
+            L.ws = carve_vit(h, h->arena, L.Bc, sp);
+            int r = vit_begin(h, L);
+            for (int i = 0; !r && i < h->vit_depth; ++i) r = vit_layer(h, L, i);
+            return r ? r : vit_end(h, L);
+        });
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(out, st_out, ob, hipMemcpyDeviceToDevice, s));
+        return KEEP_OK;
+    }
     // lanes: split the batch over n_streams concurrent sub-batches once there is enough work for each
     int lanes = h->n_streams;
     while (lanes > 1 && B < (int64_t)lanes * 32) --lanes;
@@ -911,7 +982,30 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int64_t pc_max = P < h->max_prompts ? P : h->max_prompts;
-    int rc = ensure_arena(h, txt_ws_bytes(h, pc_max, T, h->any_split()));
+    const size_t ws_bytes = align_up(txt_ws_bytes(h, pc_max, T, h->any_split()));
+    if (h->use_graphs && !h->prof_mode && P * T <= SKINNY_MAX_M && P <= h->max_prompts) {
+        // launch-bound size: stage the caller's tensors into fixed buffers and replay the whole tower as one graph
+        const size_t nb = (size_t)P * T * sizeof(int64_t), ob = (size_t)P * h->bert_H * sizeof(float);
+        int rc = ensure_arena(h, ws_bytes + 3 * align_up(nb) + align_up(ob));
+        if (rc) return rc;
+        int64_t* st_ids = (int64_t*)(h->arena + ws_bytes);
+        int64_t* st_types = (int64_t*)(h->arena + ws_bytes + align_up(nb));
+        int64_t* st_mask = (int64_t*)(h->arena + ws_bytes + 2 * align_up(nb));
+        float* st_out = (float*)(h->arena + ws_bytes + 3 * align_up(nb));
+        HIPCHK(h, hipMemcpyAsync(st_ids, ids, nb, hipMemcpyDeviceToDevice, s));
+        if (types) HIPCHK(h, hipMemcpyAsync(st_types, types, nb, hipMemcpyDeviceToDevice, s));
+        if (mask) HIPCHK(h, hipMemcpyAsync(st_mask, mask, nb, hipMemcpyDeviceToDevice, s));
+        char key[96];
+        snprintf(key, sizeof key, "txt|%lld|%lld|%d|%d", (long long)P, (long long)T, types ? 1 : 0, mask ? 1 : 0);
+        rc = graph_run(h, key, s, [&](hipStream_t cs) {
+            if (hipMemsetAsync(h->err_flag, 0, sizeof(int), cs) != hipSuccess) return h->fail(KEEP_EHIP, "memset in capture");
+            return txt_chunk(h, st_ids, types ? st_types : nullptr, mask ? st_mask : nullptr, (int)P, (int)T, st_out, cs);
+        });
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(out, st_out, ob, hipMemcpyDeviceToDevice, s));
+        return KEEP_OK;
+    }
+    int rc = ensure_arena(h, ws_bytes);
     if (rc) return rc;
     HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), s));
     for (int64_t p0 = 0; p0 < P; p0 += pc_max) {

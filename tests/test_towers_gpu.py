@@ -217,6 +217,39 @@ def test_splitk_path_matches_big_kernel(small, text_bank):
         assert ((a_img.cpu() - ref) @ text_bank.t()).abs().max() < (2e-6 if precision == "strict" else FP16_TOL)
 
 
+def test_graph_replay_is_bit_identical(small):
+    """Launch-bound calls (<= 1024 rows) are captured once and replayed as a hipGraph: same kernels, same bits; a changed
+    option or reloaded weights must invalidate the captured graph."""
+    m = make_model(small, "fp16")
+    x1, x2 = synth_tiles(1, seed=81).cuda(), synth_tiles(2, seed=82).cuda().to(torch.bfloat16)
+    toks = {k: v.cuda() for k, v in synth_prompts(3, 256, seed=83).items()}
+    m.set_option("graphs", 0)
+    ref = [m.encode_image(x1), m.encode_image(x2), m.encode_text(toks), m.encode_text({"input_ids": toks["input_ids"][:1]})]
+    m.set_option("graphs", 1)
+    for _ in range(3):                                       # capture, then replays
+        got = [m.encode_image(x1), m.encode_image(x2), m.encode_text(toks), m.encode_text({"input_ids": toks["input_ids"][:1]})]
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    # different data through the same captured graph
+    y1 = synth_tiles(1, seed=84).cuda()
+    g1 = m.encode_image(y1)
+    m.set_option("graphs", 0)
+    assert torch.equal(m.encode_image(y1), g1)
+    m.set_option("graphs", 1)
+    # an option that changes the kernels invalidates the capture
+    m.set_precision("strict")
+    s1 = m.encode_image(x1)
+    with torch.no_grad():
+        o1 = O.encode_image(small, x1.cpu())
+    assert (s1.cpu() - o1).abs().max() < 5e-6
+    # out-of-range token ids are still reported through the replayed graph
+    bad = {k: v.clone() for k, v in toks.items()}
+    bad["input_ids"][0, 3] = 10 ** 6
+    with pytest.raises(IndexError):
+        m.encode_text(bad)
+    m.encode_text(toks)
+
+
 def test_batch_chunking_is_invisible(small, no_splitk):
     m = make_model(small, "fp16")
     x = synth_tiles(7, seed=8).cuda()
