@@ -834,7 +834,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
         if (v && !g_gemm_dbg) { HIPCHK(h, hipMalloc(&g_gemm_dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(g_gemm_dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
         if (!v && g_gemm_dbg) { hipFree(g_gemm_dbg); g_gemm_dbg = nullptr; }
     }
-    else if (n == "gemm_impl") { if (v != 0 && v != 1 && v != 3 && v != 128 && v != 256 && v != 2128 && v != 3256) return h->fail(KEEP_EINVAL, "gemm_impl %d", v); g_gemm_impl = v; }
+    else if (n == "gemm_impl") { if (v != 0 && v != 1 && v != 3 && v != 128 && v != 256 && v != 2128 && v != 3256 && v != 4256) return h->fail(KEEP_EINVAL, "gemm_impl %d", v); g_gemm_impl = v; }
     else return h->fail(KEEP_EINVAL, "unknown option %s", name);
     return KEEP_OK;
 }

@@ -161,7 +161,7 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
         if (rc >= 0) return rc;
     }
     if (impl == 3 && launch_gemm_f16_v3(p, epi, s) == 0) return 0;     // persistent 256x256 variant
-    if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256) || ((impl == 256 || impl == 3256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
+    if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256 && impl != 4256) || ((impl == 256 || impl == 3256 || impl == 4256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
     launch_gemm_f16_v2(p, epi, impl, s);
     return 0;
 }

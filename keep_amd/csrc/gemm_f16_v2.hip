@@ -47,8 +47,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // <BN, WM, WN, NSTAGE>: 256x256 tile / 8 waves / 4-stage ring = one workgroup per CU (128 KiB LDS);
 //                        256x128 tile / 4 waves / 3-stage ring = TWO workgroups per CU (72 KiB LDS each): one
 //                        workgroup's prologue/epilogue then runs under the other's MFMA loop.
+// waves per SIMD the register budget is planned for: a wave tile of more than 128 accumulators (4 waves x 128x128)
+// needs the whole 512-entry file of its SIMD
+constexpr int v2_waves_per_simd(int BN, int WM, int WN) { return (V2_BM / WM / 32) * (BN / WN / 32) * 16 > 128 ? 1 : 2; }
+
 template <int BN, int WM, int WN, int NSTAGE, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, 2)
+__global__ __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BN, WM, WN))
 void gemm_f16_v2_kernel(GemmParams p) {
     constexpr int V2_THREADS = WM * WN * 64;
     constexpr int BM = V2_BM, BK = V2_BK;
@@ -249,7 +253,10 @@ void gemm_f16_v2_kernel(GemmParams p) {
     __syncthreads();
     constexpr int WN_COLS = TN * 32;                 // 64 for the 256x256 variant
     constexpr int PITCH = WN_COLS + 4;               // fp32 elements; +4 keeps ds_write_b128 conflict free
-    float* slab = reinterpret_cast<float*>(smem_raw) + wave * 2400;     // 9600 B per wave: fp32 slab 8704 B, or fp16 hi+lo slabs 2 x 4608 B
+    constexpr int PITCH16 = WN_COLS + 8;             // fp16 elements: 144-byte rows keep ds_read_b128 aligned
+    constexpr int SLAB_FLOATS = ((32 * PITCH > 32 * PITCH16 ? 32 * PITCH : 32 * PITCH16) + 63) / 64 * 64 + 96;   // fp32 slab or fp16 hi+lo slabs (2400 for 64 columns)
+    static_assert(SLAB_FLOATS * 4 * WM * WN <= NSTAGE * (V2_BM + BN) * V2_BK * 2, "epilogue slabs must fit the LDS ring");
+    float* slab = reinterpret_cast<float*>(smem_raw) + wave * SLAB_FLOATS;
     constexpr bool F16_OUT = (EPI == EPI_F16 || EPI == EPI_GELU_F16);
     constexpr int CPL = F16_OUT ? 8 : 4;             // columns per lane on the way out
     constexpr int LPR = WN_COLS / CPL;               // lanes per row
@@ -265,7 +272,6 @@ void gemm_f16_v2_kernel(GemmParams p) {
     }
     // fp16 outputs: bias (+GELU) and the fp16 conversion happen on the accumulator fragments, so only half
     // the bytes cross the LDS (its ds_write rate, ~80 B/clk/CU, was a third of this epilogue)
-    constexpr int PITCH16 = WN_COLS + 8;             // fp16 elements: 144-byte rows keep ds_read_b128 aligned
     f16* slab_hi = reinterpret_cast<f16*>(slab);
     f16* slab_lo = slab_hi + 32 * PITCH16;
     f32x4 bfrag[F16_OUT ? TN * 4 : 1];
@@ -399,6 +405,10 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
     if (p.K % V2_BK) return 1;
     if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
     if (variant == 3256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 3>(p, epi, s);   // 96 KiB LDS: leaves room for an attention workgroup on the same CU
+    // 4 waves x 128x128 (one wave per SIMD, a third fewer LDS reads per FLOP): measured 11 % SLOWER end to end -- with no
+    // partner wave on the SIMD the ~100-cycle issue cost of each of the 8 LDS-DMA instructions per step is exposed
+    // (dealing them out one per MFMA made it worse: 12.4 vs 10.3 ms on fc2).  Kept selectable as the record of that.
+    if (variant == 4256 && p.N % 256 == 0) return launch_v2<256, 2, 2, 4>(p, epi, s);
     if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
     if (variant == 2128 && p.N % 128 == 0) return launch_v2<128, 2, 2, 3>(p, epi, s);
     return 1;

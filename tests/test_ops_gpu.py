@@ -27,7 +27,7 @@ GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 40
                (2048, 1024, 1024), (1000, 256, 192)]
 
 
-@pytest.fixture(params=[1, 128, 256, 2128, 3, 0], ids=["v1_128x128", "v2_256x128", "v2_256x256", "v2_256x128_2wg", "v3_persistent", "auto_splitk"])
+@pytest.fixture(params=[1, 128, 256, 2128, 4256, 3, 0], ids=["v1_128x128", "v2_256x128", "v2_256x256", "v2_256x128_2wg", "v2_256x256_4w", "v3_persistent", "auto_splitk"])
 def gemm_impl(ops, request):
     """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile).  0 = the
     product's automatic choice, with the small-M split-K kernel taking every shape up to its 1024-row limit."""
