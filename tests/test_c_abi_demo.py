@@ -1,0 +1,58 @@
+"""The C ABI used from plain C++ (examples/c_abi_demo.cpp): no Python, no torch in the process that computes."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_demo(out):
+    from keep_amd.build import build
+    build()                                                 # libkeep_hip.so must exist to link against
+    cmd = [HIPCC, "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.cpp"),
+           "-L" + os.path.join(ROOT, "keep_amd"), "-lkeep_hip", "-Wl,-rpath," + os.path.join(ROOT, "keep_amd"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_demo_compiles_and_links_against_the_abi(tmp_path):
+    exe = build_demo(str(tmp_path / "c_abi_demo"))
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage:" in r.stderr      # argument check happens before any GPU call
+
+
+@pytest.mark.gpu
+def test_demo_matches_python_binding(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dump_state_dict import write_state_dict, write_tiles
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.synth import synth_state_dict, synth_tiles
+    exe = build_demo(str(tmp_path / "c_abi_demo"))
+    shape = small_shape(2, 2)
+    sd = synth_state_dict(shape, seed=91)
+    tiles = synth_tiles(3, seed=92).to(torch.bfloat16)
+    w, t, o = (str(tmp_path / n) for n in ("weights.bin", "tiles.bin", "out.bin"))
+    write_state_dict(sd, w)
+    write_tiles(tiles, t)
+    r = subprocess.run([exe, w, t, o], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "ViT depth 2, BERT layers 2" in r.stderr
+    got = torch.from_numpy(np.fromfile(o, dtype=np.float32).reshape(3, 768))
+    m = KEEPModel(shape)
+    m.load_state_dict(sd, strict=True)
+    m.to("cuda:0")
+    assert torch.equal(m.encode_image(tiles.cuda()).cpu(), got)
+    # strict key semantics through the raw ABI: drop one tensor -> KEEP_EKEY at finalize
+    sd2 = dict(sd); sd2.pop("visual.norm.bias")
+    write_state_dict(sd2, w)
+    r = subprocess.run([exe, w, t, o], capture_output=True, text=True)
+    assert r.returncode == 1 and "visual.norm.bias" in r.stderr
