@@ -11,6 +11,7 @@
 //                        {(x-p,y-p),(x,y-p),(x-p,y),(x,y)} in that order (float32 sum, then / count,
 //                        exactly numpy's mean over <= 4 rows)
 #include "common.h"
+#include "../../include/keep_hip.h"
 
 namespace keepk {
 
@@ -124,8 +125,97 @@ void diag_rank_kernel(const float* __restrict__ sim, int n_img, const int* __res
     if (threadIdx.x == 0) rank[row0 + row] = part[0] + part[1] + part[2] + part[3];
 }
 
+// Tile x class similarity for a handful of classes (P <= 8: the 2- and 4-column classifiers of the WSI flows and their
+// probability maps, subtyping_utils.py:69-72).  The MFMA GEMM pads N to a 128-wide tile and runs at 1.3 TB/s on this
+// shape; the job is a stream of the [N, D] features (HBM-bound), so: class vectors in registers,
+// one wave per tile row, fp32 FMA + cross-lane sum, the softmax / argmax fused behind it.
+template <int PC, int KV>
+__global__ __launch_bounds__(256)
+void sim_small_kernel(const float* __restrict__ img, const float* __restrict__ txt, int N, int P, float scale, int mode,
+                      float* __restrict__ out_f32, f16* __restrict__ out_f16, int32_t* __restrict__ amax) {
+    constexpr int D = KV * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 t[PC][KV];
+#pragma unroll
+    for (int p = 0; p < PC; ++p)
+#pragma unroll
+        for (int i = 0; i < KV; ++i)
+            t[p][i] = p < P ? *reinterpret_cast<const f32x4*>(txt + (int64_t)p * D + (i * 64 + lane) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int stride = gridDim.x * 4;
+    for (int row0 = blockIdx.x * 4 + wave; row0 < N; row0 += 2 * stride) {
+        const int row1 = row0 + stride;
+        const bool two = row1 < N;
+        f32x4 a[2][KV];
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            a[0][i] = *reinterpret_cast<const f32x4*>(img + (int64_t)row0 * D + (i * 64 + lane) * 4);
+            a[1][i] = *reinterpret_cast<const f32x4*>(img + (int64_t)(two ? row1 : row0) * D + (i * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !two) break;
+            const int row = r ? row1 : row0;
+            float v[PC];
+#pragma unroll
+            for (int p = 0; p < PC; ++p) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < KV; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(a[r][i][e], t[p][i][e], acc);
+                v[p] = wave_sum(acc);
+            }
+            if (mode == KEEP_SIM_RAW || mode == KEEP_SIM_ARGMAX) {
+                float mine = 0.f; float bv = -INFINITY; int bi = 0;
+#pragma unroll
+                for (int p = 0; p < PC; ++p) {
+                    const float x = v[p] * scale;
+                    if (lane == p) mine = x;
+                    if (p < P && x > bv) { bv = x; bi = p; }
+                }
+                if (out_f32 && lane < P) out_f32[(int64_t)row * P + lane] = mine;
+                if (mode == KEEP_SIM_ARGMAX && lane == 0) amax[row] = bi;
+            } else {                                   // softmax(scale * cos), arithmetic as row_softmax_kernel
+                float mx = -INFINITY;
+#pragma unroll
+                for (int p = 0; p < PC; ++p) if (p < P) mx = fmaxf(mx, v[p] * scale);
+                float sum = 0.f, mine = 0.f;
+#pragma unroll
+                for (int p = 0; p < PC; ++p) {
+                    if (p < P) {
+                        const float e = expf(v[p] * scale - mx);
+                        sum += e;
+                        if (lane == p) mine = e;
+                    }
+                }
+                const float y = mine * (1.0f / sum);
+                if (lane < P) {
+                    if (mode == KEEP_SIM_SOFTMAX) out_f32[(int64_t)row * P + lane] = y;
+                    else out_f16[(int64_t)row * P + lane] = (f16)y;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace keepk
 using namespace keepk;
+
+// returns 0 when handled, -1 when the shape is left to the GEMM path
+int launch_sim_small(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax,
+                     hipStream_t s) {
+    if (P > 8 || (D != 768 && D != 1024) || mode == KEEP_SIM_TOP2SCORE) return -1;
+    int blocks = (N + 7) / 8;
+    if (blocks > 256 * 12) blocks = 256 * 12;
+    dim3 g(blocks), b(256);
+    float* of = (mode == KEEP_SIM_SOFTMAX_F16) ? nullptr : (float*)out;
+    f16* oh = (mode == KEEP_SIM_SOFTMAX_F16) ? (f16*)out : nullptr;
+#define KEEP_SIM_LAUNCH(PC, KV) hipLaunchKernelGGL((sim_small_kernel<PC, KV>), g, b, 0, s, img, txt, N, P, scale, mode, of, oh, amax)
+    if (D == 768) { if (P <= 2) KEEP_SIM_LAUNCH(2, 3); else if (P <= 4) KEEP_SIM_LAUNCH(4, 3); else KEEP_SIM_LAUNCH(8, 3); }
+    else          { if (P <= 2) KEEP_SIM_LAUNCH(2, 4); else if (P <= 4) KEEP_SIM_LAUNCH(4, 4); else KEEP_SIM_LAUNCH(8, 4); }
+#undef KEEP_SIM_LAUNCH
+    return 0;
+}
 
 void launch_diag_rank(const float* sim, int rows, int n_img, const int* target, int row0, int* rank, hipStream_t s) {
     hipLaunchKernelGGL(diag_rank_kernel, dim3(rows), dim3(256), 0, s, sim, n_img, target, row0, rank);
