@@ -75,6 +75,30 @@ def get_zeroshot_classifier(model, label_map, prompts, device, add_normal=False,
     return zero_shot_classifier(model, classnames_text, templates, device, cache)
 
 
+def build_classifier_bank(KEEP_model, label_map, prompts, device, add_normal=False,
+                          cache: Optional[TextEmbeddingCache] = None) -> List[torch.Tensor]:
+    """All prompt classifiers of a prompt file at once: the loop the three scripts run over ``prompts[str(i)]``
+    (zeroshot_subtyping_WSI.py:59-63 -> ``get_zeroshot_classifier`` per prompt set) with every distinct string embedded
+    once and the per-class normalise -> mean -> renormalise (utils.py:76-80) done for all K x C columns in three tensor
+    ops instead of K x C x 4 tiny launches.  ``prompts``: the parsed prompt JSON ({"0": {"classnames", "templates"}, ...})
+    or a list of such entries.  Returns K tensors [feat_dim, C] (views of one [K, feat_dim, C] tensor)."""
+    cache = cache or TextEmbeddingCache(KEEP_model, device)
+    entries = [prompts[str(i)] for i in range(len(prompts))] if isinstance(prompts, Mapping) else list(prompts)
+    idx_to_class = {v: k for k, v in label_map.items()}
+    if add_normal:
+        idx_to_class[len(idx_to_class)] = "Normal"
+    C_ = len(idx_to_class)
+    texts = []
+    for e in entries:
+        tpl = e["templates"][0] if isinstance(e["templates"], list) else e["templates"]     # row 0 only, as utils.py:74
+        texts.extend(tpl.replace("CLASSNAME", e["classnames"][idx_to_class[c]]) for c in range(C_))
+    emb = cache.embed(texts).to(device, torch.float32)                                      # [K*C, D]
+    emb = torch.nn.functional.normalize(emb, dim=-1)           # normalize(class_embeddings, dim=-1).mean(dim=0) over ONE row
+    emb = emb / emb.norm(dim=-1, keepdim=True)                 # class_embedding /= class_embedding.norm()
+    bank = emb.reshape(len(entries), C_, -1).permute(0, 2, 1).contiguous()                  # [K, D, C]
+    return list(bank.unbind(0))
+
+
 # ------------------------------------------------------------------------------------------------
 def _engine(model) -> KEEPModel:
     m = model["model"] if isinstance(model, Mapping) else model

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Slide-level steps at BASELINE config 4/5 size (N = 100 000 tiles, K = 1782 prompt sets x C = 4 classes) on ready features."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from keep_amd import KEEPModel, wsi
+m = wsi._engine(KEEPModel())
+N, K, C, D = 100_000, 1782, 4, 768
+g = torch.Generator(device="cuda").manual_seed(0)
+feats = torch.randn(N, D, device="cuda", generator=g)
+cls = [torch.nn.functional.normalize(torch.randn(D, C, device="cuda", generator=g), dim=0) for _ in range(K)]
+gx = 400
+cells = torch.randperm(gx * 250, device="cuda")[:N]
+coords = torch.stack([(cells % gx) * 256, (cells // gx) * 256], 1).cpu().numpy()
+def t(name, f, n=5):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): r = f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    print(f"{name:58s} {dt*1e3:9.2f} ms", flush=True); return r
+fn = t("normalize features [100k,768]", lambda: wsi._normalized(m, feats))
+bank = torch.stack([c.t() for c in cls]).reshape(K * C, D).contiguous()
+sc = t(f"prompt_scores: [100k,768]x[768,{K*C}] + top-2 scores (1.09 TFLOP fp32)", lambda: wsi.prompt_scores(m, fn, cls, pre_normalized=True), 3)
+ens = t("zero_shot_prompt_select (scores + sort + merge top 50)", lambda: wsi.zero_shot_prompt_select(m, cls, feats, 50), 3)
+pr = t("probabilities softmax(10 cos) [100k,4]", lambda: wsi._probs(m, ens, feats))
+t("refine (coordinate hash + 2x2 neighbour mean)", lambda: wsi.refine(m, pr, coords, 256, True))
+t("zero_shot_subtyping end to end (given classifier)", lambda: wsi.zero_shot_subtyping(m, ens, feats, coords, 256, True))
+t("zero_shot_detection end to end", lambda: wsi.zero_shot_detection(m, ens[:, :2].contiguous(), feats, coords, 256, False))
+t("zero_shot_segment_probs end to end (dict of 100k entries)", lambda: wsi.zero_shot_segment_probs(m, ens[:, :2].contiguous(), feats, coords, 224, True), 2)
