@@ -128,6 +128,8 @@ void attention_kernel(AttnParams p) {
     const f16* base_hi = p.qkv_hi + tok0 * D3;
     const f16* base_lo = SPLIT ? p.qkv_lo + tok0 * D3 : nullptr;
 
+    long long t_start = 0, t_staged = 0;
+    if (p.dbg) t_start = __builtin_readcyclecounter();
     stage_kv<NT, ATT_THREADS>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
     if (SPLIT) stage_kv<NT, ATT_THREADS>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
     for (int k = tid; k < NKP; k += ATT_THREADS) {
@@ -139,6 +141,7 @@ void attention_kernel(AttnParams p) {
     // The K tiles arrive by LDS-DMA: nothing but this wave's own vmcnt orders them before the barrier.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.dbg) t_staged = __builtin_readcyclecounter();
 
     const int qi = lane & 15, g = lane >> 4;
     const int nq = (p.q_rows > 0 && p.q_rows < ntok) ? p.q_rows : ntok;
@@ -280,6 +283,14 @@ void attention_kernel(AttnParams p) {
             }
         }
     }
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && blockIdx.x < 65536) {
+            long long* d = p.dbg + (size_t)blockIdx.x * 4;
+            d[0] = t_start; d[1] = t_staged; d[2] = __builtin_readcyclecounter(); d[3] = 0;
+        }
+    }
 }
 
 template <int NT, bool SPLIT, int NW>
@@ -299,8 +310,11 @@ int launch_one(const AttnParams& p, hipStream_t s) {
 
 int g_attn_waves = 8;     // wavefronts per workgroup for the unsplit 13/16-tile kernels (4 or 8)
 
-int launch_attention(const AttnParams& p, hipStream_t s) {
+extern long long* g_gemm_dbg;
+int launch_attention(const AttnParams& p_in, hipStream_t s) {
     using namespace keepk;
+    AttnParams p = p_in;
+    p.dbg = g_gemm_dbg;
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
     if (p.split) {

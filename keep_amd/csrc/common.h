@@ -110,6 +110,7 @@ struct AttnParams {
     int q_rows;                           // > 0: only the first q_rows query rows of every image are computed (CLS-only last block)
     int split;                            // 0/1
     float scale;                          // 1/sqrt(64)
+    long long* dbg;                       // diagnostics: per-workgroup [start, staged, end] shader clocks (tools/attn_timeline.py)
 };
 int launch_attention(const AttnParams& p, hipStream_t s);   // returns 0 or -1 (unsupported ntok)
 
