@@ -251,9 +251,11 @@ void attention_kernel(AttnParams p) {
             for (int r = 0; r < 4; ++r) {
                 const float a0 = s[2 * u][r];
                 const float a1 = (2 * u + 1 < NT) ? s[(2 * u + 1 < NT) ? 2 * u + 1 : 0][r] : 0.f;
-                f16 h0, l0, h1, l1;
-                split_f16(a0, h0, l0); split_f16(a1, h1, l1);
-                ph[r] = h0; ph[4 + r] = h1; pl[r] = l0; pl[4 + r] = l1;
+                // probabilities lie in [0, 1]: no saturation needed (the clamp of split_f16 was 2 of the 3 VALU
+                // instructions per score here, ~400 cycles per 16-query tile)
+                const f16 h0 = (f16)a0, h1 = (f16)a1;
+                ph[r] = h0; ph[4 + r] = h1;
+                if (SPLIT) { pl[r] = (f16)(a0 - (float)h0); pl[4 + r] = (f16)(a1 - (float)h1); }
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
