@@ -68,6 +68,8 @@ enum GemmEpi : int {
     EPI_RESID_LS = 2,   // resid  += ls[n] * (acc + bias)   fp32, in place        (proj / fc2, ViT)
     EPI_PATCH    = 3,   // resid[b*197+1+p] = acc + bias + pos[1+p]               (patch embed)
     EPI_RESID_F32= 4,   // out_f32 = acc + bias + resid      (BERT pre-LN sum; may alias resid)
+    EPI_PARTIAL  = 5,   // internal: fp32 partial sums of one K slice -> splitk_ws[slice][M][N] (no bias); the
+                        // split-K reduce kernel of gemm_f16_skinny.hip then applies the real epilogue
 };
 
 struct GemmParams {
@@ -87,6 +89,7 @@ struct GemmParams {
     // launch_gemm_f16 reports through its return value whether it was applied (bit 0) -- the big kernel never does
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     f16* ln_out_hi; f16* ln_out_lo; float* ln_out_f32;   // fp16 in blk layout (KT = N / 32); fp32 row-major [M][N], may alias resid / out_f32
+    int ksplit;                           // internal (EPI_PARTIAL): number of K slices the grid is replicated over
     float* splitk_ws; size_t splitk_bytes; // scratch for the small-M split-K kernel (gemm_f16_skinny.hip); null: never used
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
     int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
@@ -95,9 +98,11 @@ struct GemmParams {
 int launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);             // blk-layout operands (product path); returns GEMM_DID_LN or 0
 constexpr int GEMM_DID_LN = 1;
 void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s);   // row-major operands (test cross-check)
-// small-M split-K path: 30 MiB of scratch covers every shape with M <= SKINNY_MAX_M (<= 768 + 1024 partial tiles of 32 x 128 fp32)
+// split-K scratch: 30 MiB cover every small-M shape (M <= SKINNY_MAX_M: <= 768 + 1024 partial tiles of 32 x 128 fp32);
+// the mid-size path (256x256 tiles x K slices when a GEMM has fewer tiles than CUs) needs <= 448 tiles of 256 KiB
 constexpr int SKINNY_MAX_M = 1024;
-constexpr size_t SKINNY_WS_BYTES = (size_t)(768 + 1024 + 64) * 32 * 128 * 4;
+constexpr size_t SKINNY_WS_BYTES = (size_t)448 * 256 * 256 * 4;
+int launch_gemm_splitk_reduce(const GemmParams& p, int epi, const float* ws, int S, hipStream_t s);   // returns 0 or GEMM_DID_LN
 int launch_gemm_f16_skinny(const GemmParams& p, int epi, float* ws, size_t ws_bytes, hipStream_t s);
 
 // Attention over a fused [M][3*D] qkv buffer (token-major; q|k|v, head-major inside each).

@@ -24,6 +24,7 @@ extern int g_attn_waves;
 extern int g_ln_impl;
 extern int g_gemm_skinny_m;
 extern int g_sgemv_m;
+extern int g_gemm_splitk_tiles;
 extern int g_gemm_ablate;
 extern long long* g_gemm_dbg;
 extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
@@ -822,6 +823,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
+    else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); g_gemm_splitk_tiles = v; }
     else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); g_sgemv_m = v; }
     else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); g_gemm_skinny_m = v; }
     else if (n == "dbg_skip_ln") h->dbg_skip_ln = v;
@@ -850,6 +852,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "graphs") return h->use_graphs;
     if (n == "gemm_skinny_m") return g_gemm_skinny_m;
     if (n == "sgemv_m") return g_sgemv_m;
+    if (n == "gemm_splitk_tiles") return g_gemm_splitk_tiles;
     if (n == "ln_impl") return g_ln_impl;
     if (n == "attn_waves") return g_attn_waves;
     if (n == "lane_skew") return h->lane_skew;
@@ -1213,7 +1216,7 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     GemmParams p{};
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.nseg = split ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
-    if (!rowmajor && M <= SKINNY_MAX_M) {          // auto mode sends small M to the split-K kernel, as the towers do
+    if (!rowmajor) {                               // auto mode may take a split-K path (small or mid-size M), as the towers do
         p.splitk_ws = t.get<float>(SKINNY_WS_BYTES / 4); p.splitk_bytes = SKINNY_WS_BYTES;
         if (!p.splitk_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
     }

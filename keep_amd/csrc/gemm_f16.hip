@@ -148,6 +148,9 @@ int g_gemm_ablate = 0;
 long long* g_gemm_dbg = nullptr;
 int g_gemm_skinny_m = 1024;  // calls with M <= this many rows take the split-K kernel (0: never).  Measured crossover
                              // against the 256x256 kernel: M = 788 (4 tiles) 3.7 vs 4.6 ms per encode_image, M = 1576 5.6 vs 4.6
+int g_gemm_splitk_tiles = 64;    // mid-size calls: a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never).
+                                 // Measured: 64 -> encode_image of 8 / 16 tiles 4.43 -> 3.27 / 4.78 -> 4.00 ms; at 160 the fp32
+                                 // partial traffic costs more than the idle CUs did (16 tiles 5.12 ms, 64 tiles 11.8 vs 9.9)
 int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
 
 int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
@@ -159,6 +162,19 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     if (impl == 0 && p.M <= g_gemm_skinny_m && p.M <= SKINNY_MAX_M && p.splitk_ws) {
         const int rc = launch_gemm_f16_skinny(p, epi, p.splitk_ws, p.splitk_bytes, s);
         if (rc >= 0) return rc;
+    }
+    if (impl == 0 && g_gemm_splitk_tiles > 0 && p.splitk_ws && p.N % 256 == 0 && p.K % 32 == 0) {
+        // Between the small-M kernel and a full machine: ceil(M/256) * N/256 tiles on 256 CUs, each walking all of K alone.
+        // Cut K into S slices (>= 8 steps each), fp32 partials, then the shared reduce + epilogue kernel.
+        const int tiles = ((p.M + 255) / 256) * (p.N / 256), KT = p.K / 32;
+        int S = tiles < g_gemm_splitk_tiles ? 256 / tiles : 1;
+        if (S > 8) S = 8;
+        if (S > KT / 8) S = KT / 8;
+        if (S >= 2 && (size_t)S * p.M * p.N * sizeof(float) <= p.splitk_bytes) {
+            GemmParams q = p;
+            q.ksplit = S;
+            if (launch_gemm_f16_v2(q, EPI_PARTIAL, 256, s) == 0) return launch_gemm_splitk_reduce(p, epi, p.splitk_ws, S, s);
+        }
     }
     if (impl == 3 && launch_gemm_f16_v3(p, epi, s) == 0) return 0;     // persistent 256x256 variant
     if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256 && impl != 4256) || ((impl == 256 || impl == 3256 || impl == 4256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;

@@ -204,6 +204,13 @@ int launch_gemm_f16_skinny(const GemmParams& p, int epi, float* ws, size_t ws_by
     const int KT = p.K / 32, per = (KT + S - 1) / S;
     dim3 grid(p.N / SK_BN, (p.M + SK_BM - 1) / SK_BM, S), block(256);
     hipLaunchKernelGGL(gemm_skinny_partial_kernel, grid, block, 0, s, p, ws, per);
+    return launch_gemm_splitk_reduce(p, epi, ws, S, s);
+}
+
+// Sum of S fp32 partial planes ws[s][M][N] + epilogue (shared by the small-M path above and the mid-size split-K
+// path of the 256x256 kernel).
+int launch_gemm_splitk_reduce(const GemmParams& p, int epi, const float* ws, int S, hipStream_t s) {
+    dim3 block(256);
     if (p.ln_gamma && p.ln_out_hi && (epi == EPI_RESID_LS || epi == EPI_RESID_F32) && p.N <= 1024) {
         if (epi == EPI_RESID_LS) hipLaunchKernelGGL(gemm_skinny_reduce_ln_kernel<EPI_RESID_LS>, dim3(p.M), block, 0, s, p, ws, S);
         else hipLaunchKernelGGL(gemm_skinny_reduce_ln_kernel<EPI_RESID_F32>, dim3(p.M), block, 0, s, p, ws, S);

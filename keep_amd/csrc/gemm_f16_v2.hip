@@ -81,7 +81,10 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // the Infinity Cache (profiles/README.md).
     const int ntn = p.N / BN;
     const int mtn = (p.M + BM - 1) / BM;
-    const int nwg = gridDim.x;
+    // split-K (EPI_PARTIAL): the grid is the tile sequence repeated once per K slice
+    const int nwg = (EPI == EPI_PARTIAL) ? ntn * mtn : (int)gridDim.x;
+    const int zsplit = (EPI == EPI_PARTIAL) ? (int)blockIdx.x / nwg : 0;
+    const int bidx = (EPI == EPI_PARTIAL) ? (int)blockIdx.x - zsplit * nwg : (int)blockIdx.x;
     constexpr int BW = 2048 / BN;             // band of n-tiles that share an A panel on one XCD (8 tiles of 256: measured 2.5 % better than 4 on fc1)
     auto tile_of = [&](int b, int& tm_, int& tn_) {
         const int xcd = b & 7, slot = b >> 3;
@@ -97,7 +100,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
         }
     };
     int tm, tn;
-    tile_of(blockIdx.x, tm, tn);
+    tile_of(bidx, tm, tn);
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
@@ -122,12 +125,17 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int64_t a_tile = (int64_t)(m0 >> 8) * KT * 8192;
     const int64_t w_tile = (int64_t)(n0 >> 8) * KT * 8192;
 
-    const int ktiles = KT;
+    int kt0 = 0, ktiles = KT;
+    if (EPI == EPI_PARTIAL) {
+        const int per = (KT + p.ksplit - 1) / p.ksplit;
+        kt0 = zsplit * per;
+        ktiles = (kt0 + per < KT ? kt0 + per : KT) - kt0;
+    }
     const int steps = ktiles * p.nseg;
 
     auto stage = [&](int s, int buf) {
         const int seg = s / ktiles;
-        const int kt = s - seg * ktiles;
+        const int kt = kt0 + (s - seg * ktiles);
         const f16* ab = ((seg == 1) ? p.a_lo : p.a_hi) + a_tile + (int64_t)kt * 8192;
         const f16* wb = ((seg == 2) ? p.w_lo : p.w_hi) + w_tile + (int64_t)kt * 8192;
         f16* sa = lds + buf * BUF_ELEMS;
@@ -267,7 +275,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     f32x4 bias4[CPL / 4], ls4[CPL / 4];
 #pragma unroll
     for (int c = 0; c < CPL / 4; ++c) {
-        bias4[c] = *reinterpret_cast<const f32x4*>(p.bias + ncol + c * 4);
+        bias4[c] = (EPI == EPI_PARTIAL) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(p.bias + ncol + c * 4);
         if (EPI == EPI_RESID_LS) ls4[c] = *reinterpret_cast<const f32x4*>(p.ls + ncol + c * 4);
     }
     // fp16 outputs: bias (+GELU) and the fp16 conversion happen on the accumulator fragments, so only half
@@ -293,7 +301,8 @@ void gemm_f16_v2_kernel(GemmParams p) {
             int prow; int64_t orow;
             gemm_epilogue_row<EPI>(p, mc, prow, orow);
             oo[it] = orow * p.N + ncol;
-            if (EPI == EPI_PATCH) res[it] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + ncol);
+            if (EPI == EPI_PARTIAL) { oo[it] = ((int64_t)zsplit * p.M + mc) * p.N + ncol; res[it] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            else if (EPI == EPI_PATCH) res[it] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + ncol);
             else res[it] = *reinterpret_cast<const f32x4*>(p.resid + oo[it]);
         }
     };
@@ -356,7 +365,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     x[e] = (EPI == EPI_RESID_LS) ? res2[j & 1][it][e] + ls4[0][e] * x[e] : res2[j & 1][it][e] + x[e];
                 }
                 if (mbase + r < p.M) {
-                    float* dst = (EPI == EPI_RESID_F32) ? p.out_f32 : p.resid;
+                    float* dst = (EPI == EPI_PARTIAL) ? p.splitk_ws : (EPI == EPI_RESID_F32) ? p.out_f32 : p.resid;
                     *reinterpret_cast<f32x4*>(dst + oo2[j & 1][it]) = x;
                 }
             }
@@ -379,16 +388,18 @@ int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
 #define KEEP_SET_ATTR(E) if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, E>), \
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
         KEEP_SET_ATTR(EPI_F16) KEEP_SET_ATTR(EPI_GELU_F16) KEEP_SET_ATTR(EPI_RESID_LS) KEEP_SET_ATTR(EPI_PATCH) KEEP_SET_ATTR(EPI_RESID_F32)
+        KEEP_SET_ATTR(EPI_PARTIAL)
 #undef KEEP_SET_ATTR
         attr_set = true;
     }
-    const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM);
+    const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM) * (epi == EPI_PARTIAL ? p.ksplit : 1);
     dim3 g(grid), b(WM * WN * 64);
     switch (epi) {
         case EPI_F16:      hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_F16>), g, b, lds_bytes, s, p); break;
         case EPI_GELU_F16: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_GELU_F16>), g, b, lds_bytes, s, p); break;
         case EPI_RESID_LS: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_RESID_LS>), g, b, lds_bytes, s, p); break;
         case EPI_PATCH:    hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_PATCH>), g, b, lds_bytes, s, p); break;
+        case EPI_PARTIAL:  hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_PARTIAL>), g, b, lds_bytes, s, p); break;
         default:           hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_RESID_F32>), g, b, lds_bytes, s, p); break;
     }
     return 0;

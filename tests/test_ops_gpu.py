@@ -35,9 +35,11 @@ def gemm_impl(ops, request):
     skinny = 1024
     if request.param == 0:
         ops.set_option("gemm_skinny_m", 1024)
+        ops.set_option("gemm_splitk_tiles", 256)           # every larger shape of the list goes through the K-sliced 256x256 path
     yield request.param
     ops.set_option("gemm_impl", 0)
     ops.set_option("gemm_skinny_m", skinny)
+    ops.set_option("gemm_splitk_tiles", 64)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)

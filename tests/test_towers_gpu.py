@@ -188,9 +188,11 @@ def no_splitk():
     from keep_amd.ops import Ops
     o = Ops()
     o.set_option("gemm_skinny_m", 0)
-    o.set_option("sgemv_m", 0)             # likewise the few-row fp32 kernel of the head / pooler
+    o.set_option("gemm_splitk_tiles", 0)   # likewise the K-sliced 256x256 path of mid-size calls
+    o.set_option("sgemv_m", 0)             # and the few-row fp32 kernel of the head / pooler
     yield
     o.set_option("gemm_skinny_m", 1024)
+    o.set_option("gemm_splitk_tiles", 64)
     o.set_option("sgemv_m", 16)
 
 
@@ -199,16 +201,22 @@ def test_splitk_path_matches_big_kernel(small, text_bank):
     from keep_amd.ops import Ops
     o = Ops()
     x = synth_tiles(3, seed=71).cuda()                       # M = 591 rows: split-K by default
+    x6 = synth_tiles(6, seed=73).cuda()
     toks = {k: v.cuda() for k, v in synth_prompts(2, 64, seed=72).items()}
     for precision, tol in (("strict", 2e-6), ("fp16", 2e-4)):
         m = make_model(small, precision)
         a_img, a_txt = m.encode_image(x), m.encode_text(toks)
         assert torch.equal(m.encode_image(x), a_img) and torch.equal(m.encode_text(toks), a_txt)
-        o.set_option("gemm_skinny_m", 0); o.set_option("sgemv_m", 0)
+        a_mid = m.encode_image(x6)                           # M = 1182 rows: 256x256 tiles cut into K slices
+        o.set_option("gemm_skinny_m", 0); o.set_option("sgemv_m", 0); o.set_option("gemm_splitk_tiles", 0)
         try:
             b_img, b_txt = m.encode_image(x), m.encode_text(toks)
+            b_mid = m.encode_image(x6)
         finally:
-            o.set_option("gemm_skinny_m", 1024); o.set_option("sgemv_m", 16)
+            o.set_option("gemm_skinny_m", 1024); o.set_option("sgemv_m", 16); o.set_option("gemm_splitk_tiles", 64)
+        d_mid = (a_mid - b_mid).abs().max().item()
+        print(f"[mid-size split-K vs 256x256 {precision}] max|dfeat|={d_mid:.3e}")
+        assert d_mid < tol and torch.equal(m.encode_image(x6), a_mid)
         d = max((a_img - b_img).abs().max().item(), (a_txt - b_txt).abs().max().item())
         print(f"[splitk vs 256x256 {precision}] max|dfeat|={d:.3e}")
         assert d < tol
