@@ -85,6 +85,7 @@ struct keep_handle {
     hipStream_t cap_stream = nullptr;
     int dbg_calls = 0;
     int dbg_skip_ln = 0;         // diagnostics (takes effect from the 4th encode_image call, so the buffers hold real data): skip the ViT block LayerNorm launches (results wrong; bounds what fusing them away could gain)
+    int lane_min_tiles = 16;     // a lane is only opened for at least this many tiles (32 tiles: 7.09 -> 6.50 ms as 2 x 16; 16 tiles as 2 x 8 loses)
     int lane_skew = 0;           // >0: lane l starts after lane l-1 finished stage `lane_skew` of block 0 (1 qkv .. 5 fc2)
     hipEvent_t ev_skew[4] = {nullptr, nullptr, nullptr, nullptr};
     int lane0_permille = 500;    // share of a 2-lane chunk given to lane 0 (experiments with workgroup-round packing)
@@ -827,6 +828,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); g_sgemv_m = v; }
     else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); g_gemm_skinny_m = v; }
     else if (n == "dbg_skip_ln") h->dbg_skip_ln = v;
+    else if (n == "lane_min_tiles") { if (v < 6) return h->fail(KEEP_EINVAL, "lane_min_tiles must be >= 6"); h->lane_min_tiles = v; }
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
     else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); g_ln_impl = v; }
@@ -867,7 +869,7 @@ int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
     size_t need = 0;
     if (tiles > 0 && h->vit_depth) {
         int lanes = h->n_streams;
-        while (lanes > 1 && tiles < (int64_t)lanes * 32) --lanes;
+        while (lanes > 1 && tiles < (int64_t)lanes * h->lane_min_tiles) --lanes;
         int64_t per = (tiles + lanes - 1) / lanes;
         if (per > h->max_tiles) per = h->max_tiles;
         need = align_up(vit_ws_bytes(h, per, h->any_split())) * lanes;
@@ -915,7 +917,7 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     }
     // lanes: split the batch over n_streams concurrent sub-batches once there is enough work for each
     int lanes = h->n_streams;
-    while (lanes > 1 && B < (int64_t)lanes * 32) --lanes;
+    while (lanes > 1 && B < (int64_t)lanes * h->lane_min_tiles) --lanes;
     int64_t per = (B + lanes - 1) / lanes;
     if (per > h->max_tiles) per = h->max_tiles;
     const bool split = h->any_split();
