@@ -93,7 +93,7 @@ int keep_bert_layers(keep_handle* h);
  *                     3 persistent (process-wide kernel selection override, for tests and A/B measurements)
  *   "graphs"          1 (default): calls of at most 1024 rows (a few prompts / tiles: ~100 dependent kernels of a few
  *                     microseconds) are captured once and replayed as one hipGraph launch; 0: always launch kernels
- *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 1024, 0 never;
+ *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 320, 0 never;
  *                     process-wide).  The two GEMM paths agree to rounding, each is bit-reproducible
  *   "gemm_splitk_tiles"  a larger call whose 256x256 tiling has fewer tiles than this (default 64, 0 never) is cut into
  *                     K slices with fp32 partials + the same reduce/epilogue kernel (8-16 tiles per call: -16..-26 %)

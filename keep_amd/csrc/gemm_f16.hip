@@ -146,8 +146,8 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
 int launch_gemm_f16_v3(const GemmParams& p, int epi, hipStream_t s);
 int g_gemm_ablate = 0;
 long long* g_gemm_dbg = nullptr;
-int g_gemm_skinny_m = 1024;  // calls with M <= this many rows take the split-K kernel (0: never).  Measured crossover
-                             // against the 256x256 kernel: M = 788 (4 tiles) 3.7 vs 4.6 ms per encode_image, M = 1576 5.6 vs 4.6
+int g_gemm_skinny_m = 320;   // calls with M <= this many rows take the register-direct split-K kernel (0: never).  Above it the
+                             // K-sliced 256x256 kernel is faster: 2 tiles (394 rows) 2.57 -> 2.36 ms, 4 tiles (788) 3.45 -> 2.83 ms
 int g_gemm_splitk_tiles = 64;    // mid-size calls: a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never).
                                  // Measured: 64 -> encode_image of 8 / 16 tiles 4.43 -> 3.27 / 4.78 -> 4.00 ms; at 160 the fp32
                                  // partial traffic costs more than the idle CUs did (16 tiles 5.12 ms, 64 tiles 11.8 vs 9.9)

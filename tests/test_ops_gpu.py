@@ -32,7 +32,7 @@ def gemm_impl(ops, request):
     """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile).  0 = the
     product's automatic choice, with the small-M split-K kernel taking every shape up to its 1024-row limit."""
     ops.set_option("gemm_impl", request.param)
-    skinny = 1024
+    skinny = 320
     if request.param == 0:
         ops.set_option("gemm_skinny_m", 1024)
         ops.set_option("gemm_splitk_tiles", 256)           # every larger shape of the list goes through the K-sliced 256x256 path
