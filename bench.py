@@ -61,7 +61,7 @@ def cpu_model_name() -> str:
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(sd, tiles: int = 8, iters: int = 3):
+def cpu_baseline(sd, tiles: int = 8, iters: int = 40, min_seconds: float = 10.0):
     """The oracle (fp32 torch-CPU restatement of the reference's encode_image) on the host cores."""
     from oracle import keep_oracle as O
     torch.set_num_threads(min(usable_cpus(), 64))
@@ -73,7 +73,7 @@ def cpu_baseline(sd, tiles: int = 8, iters: int = 3):
         for _ in range(iters):
             O.encode_image(sd, x)
             done += 1
-            if time.perf_counter() - t0 > 30.0:                     # bounded sample
+            if time.perf_counter() - t0 > min_seconds:              # bounded sample: ~10 s of CPU work
                 break
         dt = time.perf_counter() - t0
     iters = done
