@@ -873,10 +873,14 @@ int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
         int64_t per = (tiles + lanes - 1) / lanes;
         if (per > h->max_tiles) per = h->max_tiles;
         need = align_up(vit_ws_bytes(h, per, h->any_split())) * lanes;
+        if (tiles * 197 <= SKINNY_MAX_M)          // graph-replayed call: + staged pixels (fp32 at most) and outputs
+            need += align_up((size_t)tiles * 3 * 224 * 224 * 4) + align_up((size_t)tiles * h->proj_dim * 4);
     }
     if (prompts > 0 && seq > 0 && h->bert_layers) {
         const int64_t pc = prompts < h->max_prompts ? prompts : h->max_prompts;
-        const size_t t = txt_ws_bytes(h, pc, seq, h->any_split());
+        size_t t = align_up(txt_ws_bytes(h, pc, seq, h->any_split()));
+        if (prompts * seq <= SKINNY_MAX_M)        // graph-replayed call: + staged ids / types / mask and outputs
+            t += 3 * align_up((size_t)prompts * seq * 8) + align_up((size_t)prompts * h->bert_H * 4);
         need = t > need ? t : need;
     }
     return ensure_arena(h, need);
