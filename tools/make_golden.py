@@ -77,7 +77,7 @@ def hf_dinov2_from_sd(sd, depth):
     return m
 
 
-def golden_vit(depth: int, batch: int, seed: int):
+def golden_vit(depth: int, batch: int, seed: int, name: str = None):
     shape = small_shape(vit_depth=depth) if depth != 24 else KEEPShape()
     sd = synth_state_dict(shape, seed=seed, text=False)
     x = synth_tiles(batch, seed=seed + 100)
@@ -96,7 +96,7 @@ def golden_vit(depth: int, batch: int, seed: int):
     d_feat = float((feat_or - feat_hf).abs().max())
     print(f"[vit d{depth}] oracle vs Dinov2: max|dtok|={d_tok:.3e} max|dfeat|={d_feat:.3e}")
     assert d_tok < 5e-4 and d_feat < 2e-6, "oracle image tower disagrees with Dinov2-as-ViT-L"
-    np.savez_compressed(os.path.join(GOLD, f"vit_d{depth}.npz"),
+    np.savez_compressed(os.path.join(GOLD, name or f"vit_d{depth}.npz"),
                         depth=depth, batch=batch, weight_seed=seed, tile_seed=seed + 100,
                         tiles_checksum=checksum(x), qkv0_checksum=checksum(sd["visual.blocks.0.attn.qkv.weight"]),
                         cls=cls_hf.numpy(), features=feat_hf.numpy(),
@@ -332,7 +332,7 @@ def golden_tile_eval(seed: int = 9):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["wsi", "tile_eval", "bert2", "bert12", "vit2", "vit24"]
+    which = sys.argv[1:] or ["wsi", "tile_eval", "bert2", "bert12", "vit2", "vit24", "vit24_bench"]
     if "tile_eval" in which:
         golden_tile_eval()
     if "wsi" in which:
@@ -345,6 +345,8 @@ def main():
         golden_vit(2, 3, seed=21)
     if "vit24" in which:
         golden_vit(24, 2, seed=22)
+    if "vit24_bench" in which:          # the weights bench.py runs on (seed 0): lets the bench print a live parity figure
+        golden_vit(24, 8, seed=0, name="vit_d24_bench.npz")
 
 
 if __name__ == "__main__":
