@@ -265,6 +265,34 @@ def test_graph_replay_is_bit_identical(small):
     m.encode_text(toks)
 
 
+def test_every_path_boundary_agrees_with_the_plain_path(small):
+    """Batch sizes on both sides of every dispatch threshold (register-direct split-K <= 320 rows, graph replay <= 1024 rows,
+    K-sliced 256x256 below 64 tiles, second lane from 16 tiles per lane, 256-tile sub-batches): the default engine must
+    agree with the plain one (256x256 kernel only, one stream, no graphs) to rounding."""
+    from keep_amd.ops import Ops
+    o = Ops()
+    sizes = (1, 2, 5, 6, 8, 13, 16, 17, 31, 32, 33, 64, 65, 100, 257)
+    x = synth_tiles(max(sizes), seed=77).cuda().to(torch.bfloat16)
+    toks = {k: v.cuda() for k, v in synth_prompts(70, 64, seed=78).items()}
+    for precision, tol in (("strict", 3e-6), ("fp16", 3e-4)):
+        m = make_model(small, precision)
+        got = {b: m.encode_image(x[:b]) for b in sizes}
+        got_t = {pn: m.encode_text({k: v[:pn] for k, v in toks.items()}) for pn in (1, 5, 16, 17, 64, 70)}
+        for k, v in (("gemm_skinny_m", 0), ("gemm_splitk_tiles", 0), ("sgemv_m", 0)):
+            o.set_option(k, v)
+        m.set_option("graphs", 0); m.set_option("streams", 1)
+        try:
+            plain = m.encode_image(x)
+            plain_t = m.encode_text(toks)
+        finally:
+            for k, v in (("gemm_skinny_m", 320), ("gemm_splitk_tiles", 64), ("sgemv_m", 16)):
+                o.set_option(k, v)
+        worst = max((got[b] - plain[:b]).abs().max().item() for b in sizes)
+        worst_t = max((got_t[pn] - plain_t[:pn]).abs().max().item() for pn in got_t)
+        print(f"[path boundaries {precision}] image max|dfeat|={worst:.3e} text {worst_t:.3e}")
+        assert worst < tol and worst_t < tol
+
+
 def test_batch_chunking_is_invisible(small, no_splitk):
     m = make_model(small, "fp16")
     x = synth_tiles(7, seed=8).cuda()
