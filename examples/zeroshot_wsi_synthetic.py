@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keep_amd import KEEPModel, wsi                                   # noqa: E402
 from keep_amd.config import KEEPShape, small_shape                    # noqa: E402
 from keep_amd.distributed import encode_tiles_sharded                 # noqa: E402
-from keep_amd.synth import synth_prompts, synth_state_dict            # noqa: E402
+from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles_device   # noqa: E402
 
 
 def main():
@@ -44,14 +44,13 @@ def main():
     model.load_state_dict(synth_state_dict(shape, seed=0))
     model.to(dev).eval()
 
-    # tiles are generated on the device, per tile index (so every world size sees the same slide)
+    # tiles are generated on the device in units of 256 (a tile's pixels depend only on its global index, so every
+    # world size sees the same slide); one or two randn launches per batch, no per-tile Python work
     def load_tiles(a, b):
-        out = torch.empty(b - a, 3, 224, 224, device=dev, dtype=torch.bfloat16)
-        for i in range(a, b):
-            g = torch.Generator(device=dev).manual_seed(1000 + i)
-            out[i - a] = torch.randn(3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
-        return out
+        return synth_tiles_device(a, b, dev, torch.bfloat16, seed=1000)
 
+    model.reserve(tiles=256)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     feats = encode_tiles_sharded(model.encode_image, args.tiles, load_tiles, batch=256)
     torch.cuda.synchronize()

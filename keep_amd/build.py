@@ -8,6 +8,8 @@ travels with the repo snapshot to the GPU box.
 from __future__ import annotations
 
 import concurrent.futures
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -27,14 +29,36 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
 
 
-def _deps():
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_epilogue.h"),
-             os.path.join(HERE, "..", "include", "keep_hip.h")]
-    return max(os.path.getmtime(f) for f in files)
+HEADERS = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "keep_hip.h")]
+MANIFEST = os.path.join(HERE, "build", "manifest.json")
+
+
+def _sha(paths, extra="") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _source_keys(defines):
+    """One content hash per object: the source, every header and the flags (mtimes play no part: the prebuilt .so that
+    travels with a snapshot has arbitrary timestamps)."""
+    hdr = _sha(HEADERS, " ".join(FLAGS + list(defines)))
+    return {s: _sha([os.path.join(CSRC, s)], hdr) for s in SOURCES}
+
+
+def _read_manifest(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def up_to_date() -> bool:
-    return os.path.exists(OUT) and os.path.getmtime(OUT) >= _deps()
+    m = _read_manifest(MANIFEST)
+    return os.path.exists(OUT) and m.get("objects") == _source_keys([]) and m.get("lib") == _sha([OUT])
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -45,16 +69,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if defines or out != OUT:
         return _build(out, os.path.join(HERE, "build_" + os.path.basename(out)), defines, verbose)
     if not force and up_to_date():
+        if verbose:
+            print(f"build: {OUT} matches the content hashes of its {len(SOURCES)} sources: recompiled 0 objects")
         return OUT
-    return _build(OUT, os.path.join(HERE, "build"), [], verbose)
+    return _build(OUT, os.path.join(HERE, "build"), [], verbose, force)
 
 
-def _build(OUT: str, objdir: str, defines, verbose: bool) -> str:
+def _build(OUT: str, objdir: str, defines, verbose: bool, force: bool = False) -> str:
     cc = hipcc()
     os.makedirs(objdir, exist_ok=True)
+    manifest_path = os.path.join(objdir, "manifest.json")
+    old = {} if force else _read_manifest(manifest_path).get("objects", {})
+    keys = _source_keys(defines)
+    recompiled = []
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if old.get(src) == keys[src] and os.path.exists(obj):
+            return obj
+        recompiled.append(src)
         cmd = [cc, *FLAGS, *defines, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -68,8 +101,10 @@ def _build(OUT: str, objdir: str, defines, verbose: bool) -> str:
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    with open(manifest_path, "w") as f:
+        json.dump({"objects": keys, "lib": _sha([OUT])}, f, indent=1)
     if verbose:
-        print(f"built {OUT}")
+        print(f"build: recompiled {len(recompiled)} objects ({', '.join(sorted(recompiled)) or 'none'}), linked {OUT}")
     return OUT
 
 

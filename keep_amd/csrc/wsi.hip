@@ -46,8 +46,11 @@ void group_top2_reduce_kernel(const float* __restrict__ partial, int nrb, int K,
 }
 
 // ---- coordinate hash: open addressing on packed (x, y), value = smallest tile index with that key
+// Coordinates must fit int32 (the Python wrapper checks; slides are < 2^20 pixels wide).  Each half is stored with its sign
+// bit flipped, so the all-ones EMPTY_KEY would be (INT32_MAX, INT32_MAX) -- outside what the wrapper admits -- and the
+// neighbour (-1, -1) of a tile at (patch-1, patch-1) is an ordinary key.
 __device__ __forceinline__ unsigned long long pack_xy(long long x, long long y) {
-    return ((unsigned long long)(unsigned)(int)x << 32) | (unsigned long long)(unsigned)(int)y;
+    return ((unsigned long long)(unsigned)((int)x ^ 0x80000000) << 32) | (unsigned long long)(unsigned)((int)y ^ 0x80000000);
 }
 __device__ __forceinline__ unsigned hash_xy(unsigned long long k, unsigned mask) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
@@ -72,8 +75,8 @@ __device__ __forceinline__ int coord_lookup(const unsigned long long* keys, cons
     unsigned s = hash_xy(key, mask);
     while (true) {
         const unsigned long long k = keys[s];
-        if (k == key) return first[s];
         if (k == EMPTY_KEY) return -1;
+        if (k == key) return first[s];
         s = (s + 1) & mask;
     }
 }

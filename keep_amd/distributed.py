@@ -1,10 +1,15 @@
 """Multi-GPU sharding of a slide's tiles: one process per GPU, contiguous tile shards,
-no data-path collective inside the encoders, ONE all-gather of the per-tile embeddings for the
+no data-path collective inside the encoders, and an all-gather of the per-tile embeddings for the
 slide-level steps that need every tile (prompt screening means, spatial refine).
 
 Works with any initialised ``torch.distributed`` backend: ``nccl`` (= RCCL over xGMI on MI355X) for
 GPU tensors, ``gloo`` for the CPU tests.  The reference has no inference-side multi-GPU code
 (WSI scripts pin ``device='cuda:0'``, e.g. zeroshot_subtyping_WSI.py:26); this is new.
+
+The exchange is pipelined: every rank encodes its shard in batches of ``batch`` tiles, and the all-gather of
+batch j (``[batch, D]`` per rank, 0.79 MB at 256 x 768 fp32) is issued asynchronously while batch j+1 is being
+encoded, so the collective never sits on the critical path; the gathered ``[n_batches, world, batch, D]`` slab is
+un-padded into ``[n_tiles, D]`` with ONE index_select (no per-rank Python copies).
 """
 from __future__ import annotations
 
@@ -27,10 +32,21 @@ def shard_capacity(n_items: int, world: int) -> int:
     return -(-n_items // world)
 
 
+def _owner_and_offset(n_total: int, world: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """For every global row: the rank that holds it under ``shard_bounds`` and its offset inside that shard."""
+    g = torch.arange(n_total, device=device, dtype=torch.int64)
+    q, rem = divmod(n_total, world)
+    head = rem * (q + 1)                                  # rows held by the ranks that carry one extra item
+    rank = torch.where(g < head, g // (q + 1), rem + (g - head) // max(q, 1))
+    lo = rank * q + torch.clamp(rank, max=rem)
+    return rank, g - lo
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """Gather row-sharded ``local`` ([n_local, D], partition = shard_bounds) into [n_total, D] on every rank.
 
-    Shards are padded to the common capacity so a single ``all_gather_into_tensor`` moves everything.
+    Shards are padded to the common capacity so a single ``all_gather_into_tensor`` moves everything; the
+    padding is dropped with one index_select.
     """
     if not (dist.is_available() and dist.is_initialized()):
         if local.shape[0] != n_total:
@@ -42,28 +58,53 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
         raise ValueError(f"rank {rank} holds {local.shape[0]} rows, expected {hi - lo}")
     cap = shard_capacity(n_total, world)
     D = local.shape[1]
-    send = local.new_zeros((cap, D))
-    send[: hi - lo] = local
+    if hi - lo == cap:
+        send = local.contiguous()
+    else:
+        send = local.new_zeros((cap, D))
+        send[: hi - lo] = local
     recv = local.new_empty((world * cap, D))
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
-    out = local.new_empty((n_total, D))
-    for r in range(world):
-        a, b = shard_bounds(n_total, r, world)
-        out[a:b] = recv[r * cap: r * cap + (b - a)]
-    return out
+    dist.all_gather_into_tensor(recv, send, group=group)
+    if n_total == world * cap:
+        return recv
+    owner, off = _owner_and_offset(n_total, world, local.device)
+    return recv.index_select(0, owner * cap + off)
 
 
 def encode_tiles_sharded(encode: Callable[[torch.Tensor], torch.Tensor], n_tiles: int,
                          load_tiles: Callable[[int, int], torch.Tensor], batch: int = 256, group=None) -> torch.Tensor:
     """Each rank encodes tiles [lo, hi) in batches with ``encode`` (e.g. KEEPModel.encode_image) and all
     ranks receive the full [n_tiles, D] embedding matrix."""
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
     lo, hi = shard_bounds(n_tiles, rank, world)
-    parts = [encode(load_tiles(s, min(s + batch, hi))) for s in range(lo, hi, batch)]
-    if parts:
-        local = torch.cat(parts, dim=0)
-    else:
-        probe = encode(load_tiles(0, 1))            # only to learn D / dtype / device for an empty shard
-        local = probe[:0]
-    return all_gather_rows(local, n_tiles, group)
+    cap = shard_capacity(n_tiles, world)
+    nb = max(1, -(-cap // batch))                         # every rank issues the same number of collectives
+    slab = None                                           # [nb, world, batch, D], allocated once D / dtype / device are known
+    pending = []
+    for j in range(nb):
+        a, b = min(lo + j * batch, hi), min(lo + (j + 1) * batch, hi)
+        if b > a:
+            f = encode(load_tiles(a, b))
+        elif slab is None:
+            f = encode(load_tiles(0, 1))[:0]              # empty shard: only to learn D / dtype / device
+        else:
+            f = slab.new_empty((0, slab.shape[-1]))
+        if slab is None:
+            slab = f.new_empty((nb, world, batch, f.shape[1]))
+        if not distributed:
+            slab[j, 0, : b - a] = f
+            continue
+        if b - a == batch:
+            send = f.contiguous()
+        else:
+            send = f.new_zeros((batch, f.shape[1]))
+            send[: b - a] = f
+        # async: the collective of batch j runs while batch j+1 is encoded; `send` stays referenced until waited for
+        pending.append((dist.all_gather_into_tensor(slab[j].view(world * batch, -1), send, group=group, async_op=True), send))
+    for work, _ in pending:
+        work.wait()
+    owner, off = _owner_and_offset(n_tiles, world, slab.device)
+    pos = (off // batch) * (world * batch) + owner * batch + off % batch
+    return slab.view(nb * world * batch, -1).index_select(0, pos)

@@ -100,3 +100,19 @@ def synth_prompts(n: int, seq: int = 256, seed: int = 1, vocab: int = 30522,
     ids[torch.arange(n), lens - 1] = 3              # [SEP]
     ids = ids * mask                                # [PAD] = 0
     return {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": mask}
+
+
+def synth_tiles_device(a: int, b: int, device, dtype=torch.bfloat16, seed: int = 1000, unit: int = 256) -> torch.Tensor:
+    """Tiles [a, b) of an endless synthetic slide, generated ON the device.
+
+    The slide is defined in units of ``unit`` tiles (unit u = randn seeded with seed + u), so a tile's pixels depend
+    only on its global index: every world size / shard boundary / batch size sees the same slide, and a batch costs
+    one or two ``randn`` launches instead of a Python loop over tiles."""
+    if b <= a:
+        return torch.empty((0, 3, 224, 224), device=device, dtype=dtype)
+    parts = []
+    for u in range(a // unit, (b - 1) // unit + 1):
+        g = torch.Generator(device=device).manual_seed(seed + u)
+        block = torch.randn(unit, 3, 224, 224, device=device, generator=g, dtype=torch.float32)
+        parts.append(block[max(a - u * unit, 0): min(b - u * unit, unit)].to(dtype))
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)

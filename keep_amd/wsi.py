@@ -184,7 +184,11 @@ def refine(model, probs: torch.Tensor, tile_coords, patch_size: int, overlap: bo
     U distinct coordinates in first-seen order (the key order of the reference's dicts)."""
     m = _engine(model)
     p = probs.to(m._device, torch.float32).contiguous()
-    coords = torch.as_tensor(np.asarray(tile_coords)).to(m._device, torch.int64).contiguous()
+    coords = torch.as_tensor(np.asarray(tile_coords)).to(torch.int64)
+    lim = 2 ** 31 - 1 - abs(int(patch_size))
+    if coords.numel() and (int(coords.min()) < -lim or int(coords.max()) > lim):
+        raise ValueError("tile coordinates must fit int32 (the device-side coordinate hash packs (x, y) into 64 bits)")
+    coords = coords.to(m._device).contiguous()
     N, Cc = p.shape
     out = torch.empty_like(p)
     first = torch.empty(N, dtype=torch.int32, device=m._device)

@@ -50,7 +50,7 @@ def _worker(rank, world, port, n_tiles, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_tiles", [(2, 101), (2, 64), (3, 50), (2, 1)])
+@pytest.mark.parametrize("world,n_tiles", [(2, 101), (2, 64), (3, 50), (2, 1), (3, 2), (2, 33)])
 def test_sharded_encode_matches_single_process(world, n_tiles):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -63,6 +63,23 @@ def test_sharded_encode_matches_single_process(world, n_tiles):
         assert p.exitcode == 0
     results = dict(q.get(timeout=5) for _ in range(world))
     assert all(results[r] for r in range(world)), results
+
+
+def test_owner_offset_map_is_the_inverse_of_shard_bounds():
+    from keep_amd.distributed import _owner_and_offset
+    for n in (1, 2, 7, 64, 101, 1000):
+        for world in (1, 2, 3, 8):
+            owner, off = _owner_and_offset(n, world, "cpu")
+            for r in range(world):
+                lo, hi = shard_bounds(n, r, world)
+                assert torch.equal(owner[lo:hi], torch.full((hi - lo,), r)) and torch.equal(off[lo:hi], torch.arange(hi - lo))
+
+
+def test_single_process_sharded_encode_without_process_group():
+    g = torch.Generator().manual_seed(1)
+    tiles = torch.randn(37, 3, 4, 4, generator=g)
+    out = encode_tiles_sharded(fake_encode, 37, lambda a, b: tiles[a:b], batch=8)
+    assert torch.equal(out, fake_encode(tiles))
 
 
 def test_single_process_passthrough():

@@ -1,0 +1,67 @@
+"""The RCCL path on the hardware that is available to the tests: ONE MI355X, backend `nccl`, world_size 1.
+
+The sharding / un-padding logic for world_size > 1 is covered on gloo (tests/test_distributed_cpu.py); what only a GPU
+can show is that the `nccl` process group initialises, that `all_gather_into_tensor` on device buffers written by the
+engine's own streams is ordered correctly against them, and that bench.py's distributed leg runs end to end."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_sharded_encode_through_rccl_matches_direct_call(nccl_world1):
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.distributed import all_gather_rows, encode_tiles_sharded
+    from keep_amd.synth import synth_state_dict, synth_tiles_device
+    dev = torch.device("cuda", 0)
+    shape = small_shape(2, 2)
+    m = KEEPModel(shape)
+    m.load_state_dict(synth_state_dict(shape, seed=3, text=False), strict=False)
+    m.to(dev).eval()
+    n = 150                                                  # ragged: 4 full batches of 32 + one of 22
+    load = lambda a, b: synth_tiles_device(a, b, dev, torch.bfloat16, seed=77, unit=64)
+    got = encode_tiles_sharded(m.encode_image, n, load, batch=32)
+    ref = torch.cat([m.encode_image(load(a, min(a + 32, n))) for a in range(0, n, 32)])
+    assert got.shape == (n, shape.projection_dim)
+    assert torch.equal(got, ref)                             # same kernels, same batches: bit-identical
+    assert torch.equal(all_gather_rows(ref, n), ref)
+    # device-side tile generation depends on the global tile index only
+    assert torch.equal(load(10, 100), torch.cat([load(10, 64), load(64, 100)]))
+
+
+def test_bench_distributed_leg_runs_on_nccl():
+    env = dict(os.environ, KEEP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--no-cpu-baseline", "--no-breakdown", "--no-configs"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert "RCCL" in line["config"]["exchange"]

@@ -329,6 +329,42 @@ def golden_tile_eval(seed: int = 9):
                         p10=res["zeroshot-ret-p@10"], p50=res["zeroshot-ret-p@50"])
 
 
+def golden_c3(n_tiles: int = 4096, chunk: int = 256, n_prompts: int = 64):
+    """BASELINE.json config 3 (full dual tower: 4096 tiles x 64 prompts, sim matrix + argmax) on the bench weights
+    (seed 0).  Oracle only (it is pinned against BertModel / Dinov2Model by the sections above).  Tiles are
+    regenerated from per-chunk seeds on the GPU box, so only the expected outputs are stored: the [4096,64] fp32 cosine
+    matrix, its row argmax, the text features, and the image features of the first chunk."""
+    import time
+    sd = synth_state_dict(KEEPShape(), seed=0)
+    toks = synth_prompts(n_prompts, 256, seed=1)
+    feats = []
+    t0 = time.time()
+    with torch.no_grad():
+        txt = O.encode_text(sd, toks)
+        for c in range(n_tiles // chunk):
+            ck = f"/tmp/c3_chunk_{c}.pt"              # resumable: ~90 s of CPU per chunk
+            if os.path.exists(ck):
+                feats.append(torch.load(ck))
+                continue
+            x = synth_tiles(chunk, seed=5000 + c)
+            part = torch.cat([O.encode_image(sd, x[i:i + 32]) for i in range(0, chunk, 32)])
+            torch.save(part, ck)
+            feats.append(part)
+            print(f"[c3] chunk {c + 1}/{n_tiles // chunk}  {time.time() - t0:.0f}s", flush=True)
+    img = torch.cat(feats)
+    sims = img @ txt.t()
+    top2 = sims.topk(2, dim=1).values
+    np.savez_compressed(os.path.join(GOLD, "c3_dual_tower.npz"),
+                        n_tiles=n_tiles, chunk=chunk, tile_seed0=5000, weight_seed=0, prompt_seed=1,
+                        tiles0_checksum=checksum(synth_tiles(chunk, seed=5000)),
+                        input_ids=toks["input_ids"].numpy().astype(np.int32),
+                        attention_mask=toks["attention_mask"].numpy().astype(np.int8),
+                        txt=txt.numpy(), img_first=img[:chunk].numpy(),
+                        sims=sims.numpy(), argmax=sims.argmax(1).numpy().astype(np.int16),
+                        margin=(top2[:, 0] - top2[:, 1]).numpy())
+    print(f"[c3] {n_tiles} x {n_prompts}: min top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.3e}")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -347,6 +383,8 @@ def main():
         golden_vit(24, 2, seed=22)
     if "vit24_bench" in which:          # the weights bench.py runs on (seed 0): lets the bench print a live parity figure
         golden_vit(24, 8, seed=0, name="vit_d24_bench.npz")
+    if "c3" in which:                   # ~15 min of CPU: not in the default list
+        golden_c3()
 
 
 if __name__ == "__main__":
