@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="tiles per GPU per step")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "strict"])
+    ap.add_argument("--precision", default="comp", choices=["comp", "fp16", "strict"])
     ap.add_argument("--pixel-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (e.g. gemm_impl=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,7 +229,7 @@ def main():
             "metric": "224x224 tiles encoded/sec (whole node)", "value": round(tiles_per_s, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "fp16x3",
+            "vs_baseline": None, "dtype": {"fp16": "fp16", "comp": "fp16+mxfp4", "strict": "fp16x3"}[args.precision],
             "data": "synthetic (randn tiles generated on device, seeded random-init weights)",
             "config": {"workload": "ViT-L/16 image encoder only (KEEP encode_image), batch 256 synthetic 224x224 "
                                    f"{args.pixel_dtype} tiles per GPU, 1xMI355X per rank",

@@ -52,8 +52,13 @@ enum {
 
 /* precision modes (keep_set_option "precision") */
 enum {
-    KEEP_PREC_FP16 = 0,   /* fp16 MFMA operands, fp32 accumulate, fp32 residual/LN/softmax/GELU    */
-    KEEP_PREC_STRICT = 1  /* hi/lo split operands, 3 MFMA passes: fp32-class accuracy, ~1/3 speed   */
+    KEEP_PREC_FP16 = 0,   /* fp16 MFMA operands, fp32 accumulate, fp32 residual/LN/softmax/GELU: fastest, cosines    */
+                          /* within ~1.5e-4 of the fp32 reference (outside the 1e-4 north-star tolerance)          */
+    KEEP_PREC_STRICT = 1, /* hi/lo split operands, 3 MFMA passes: fp32-class accuracy (4e-7), ~0.4x the speed       */
+    KEEP_PREC_COMP = 2    /* DEFAULT.  fp16 pass + the two first-order correction terms where the error budget     */
+                          /* needs them: image-tower MLP GEMMs of the first `comp_mlp_blocks` blocks on the MX-fp4  */
+                          /* MFMA pipe, attention side of the first `comp_full_blocks` blocks and the whole text    */
+                          /* tower as split products.  Cosines within 1e-4 of the fp32 reference.                   */
 };
 
 const char* keep_version(void);
@@ -80,8 +85,11 @@ int keep_vit_depth(keep_handle* h);
 int keep_bert_layers(keep_handle* h);
 
 /* ---- options ----------------------------------------------------------------------------------
- *   "precision"       KEEP_PREC_FP16 (default) | KEEP_PREC_STRICT
+ *   "precision"       KEEP_PREC_COMP (default) | KEEP_PREC_FP16 | KEEP_PREC_STRICT
  *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
+ *   "comp_full_blocks" KEEP_PREC_COMP: ViT blocks whose qkv / attention / proj run as split products (default 2)
+ *   "comp_mlp_blocks"  KEEP_PREC_COMP: ViT blocks whose fc1 / fc2 run as compensated products (default 12)
+ *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
  *   "max_tiles"       tiles per internal sub-batch of keep_encode_image (default 256)
  *   "max_prompts"     prompts per internal sub-batch of keep_encode_text (default 64)
  *   "streams"         concurrent sub-batches inside keep_encode_image (default 2, 1..4): the batch is split
@@ -89,19 +97,18 @@ int keep_bert_layers(keep_handle* h);
  *                     back onto the caller's stream with events (no host synchronisation)
  *   "cls_tail"        1 (default): in the last ViT block run proj / MLP for the CLS rows only (exact: the
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
- *   "gemm_impl"       0 auto | 1 128x128 register-staged | 128 / 256 / 2128 / 3256: LDS-DMA tile variants |
- *                     3 persistent (process-wide kernel selection override, for tests and A/B measurements)
+ *   "gemm_impl"       0 auto | 128 | 256: LDS-DMA tile width override (-DKEEP_EXPERIMENTS builds also accept the
+ *                     measured-negative variants 1, 3, 2128, 3256, 4256).  Like every option it belongs to the handle.
  *   "graphs"          1 (default): calls of at most 1024 rows (a few prompts / tiles: ~100 dependent kernels of a few
  *                     microseconds) are captured once and replayed as one hipGraph launch; 0: always launch kernels
- *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 320, 0 never;
- *                     process-wide).  The two GEMM paths agree to rounding, each is bit-reproducible
+ *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 320, 0 never).  The two GEMM paths agree to rounding, each is bit-reproducible
  *   "gemm_splitk_tiles"  a larger call whose 256x256 tiling has fewer tiles than this (default 64, 0 never) is cut into
  *                     K slices with fp32 partials + the same reduce/epilogue kernel (8-16 tiles per call: -16..-26 %)
  *   "sgemv_m"         same for the few-row fp32 kernel of the projection head / pooler / similarity (default 16)
  *   "ln_impl"         1 (default) LayerNorm with LDS-transposed K-blocked stores | 0 per-row stores
  *   "attn_waves"      wavefronts per attention workgroup, 8 (default) | 4
  *   "lane0_permille", "lane_skew"   experiments with the two-lane schedule (defaults 500 / 0 measured best)
- *   "gemm_ablate", "gemm_dbg"       diagnostics for tools/gemm_timeline.py (results are wrong when ablating)
+ *   "gemm_ablate", "gemm_dbg", "dbg_skip_ln"   timing diagnostics (results are wrong when ablating): -DKEEP_DIAGNOSTICS builds only
  */
 int keep_set_option(keep_handle* h, const char* name, double value);
 double keep_get_option(keep_handle* h, const char* name);
@@ -180,11 +187,18 @@ int keep_profile_reset(keep_handle* h);
  * keep_op_linear: out = epilogue(A[M,K] @ W[N,K]^T + bias) through the fp16 MFMA GEMM.
  *   epi 0: out[M,N] = acc+bias            1: gelu(acc+bias)
  *       2: out = resid + ls*(acc+bias)    4: out = resid + acc + bias      (resid, ls fp32)
- *   split != 0 runs the 3-pass hi/lo product.  Outputs of epi 0/1 are the fp16-rounded values
- *   (hi, or hi+lo in split mode) converted back to fp32. */
+ *   split 1 runs the 3-pass hi/lo product, split 2 the compensated product (fp16 pass + MX-fp4 correction terms;
+ *   N % 256 == 0, K % 64 == 0, epi 0..2).  Outputs of epi 0/1 are the fp16-rounded values (hi, or hi+lo when
+ *   split != 0) converted back to fp32. */
 int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls,
                    const float* resid, int64_t M, int64_t N, int64_t K, int epi, int split, float* out,
                    void* stream);
+/* One MLP half of a ViT block through the tower's own kernels (timm Block: x + ls2 * fc2(gelu(fc1(norm2(x))))):
+ *   LayerNorm (writes the fp16 operand and, per mode, its lo plane / MX-fp4 side planes) -> fc1 + GELU -> fc2 + LayerScale + residual.
+ *   mode 0 plain fp16 | 1 split | 2 compensated.  x, out fp32 [M, D]; D in {768, 1024}; F % 256 == 0. */
+int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* ln_b, const float* fc1_w, const float* fc1_b,
+                const float* fc2_w, const float* fc2_b, const float* ls, int64_t M, int64_t D, int64_t F, int mode, float* out,
+                void* stream);
 /* qkv fp32 [B*T, 3*heads*64] (q|k|v), mask int64 [B,T] or NULL -> out fp32 [B*T, heads*64] */
 int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int64_t B, int64_t T, int heads,
                       int split, float* out, void* stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("KEEP_HIP_LIB") or os.path.join(_HERE, "libkeep_hip.so
 KEEP_OK, KEEP_EINVAL, KEEP_ESTATE, KEEP_EKEY, KEEP_EHIP, KEEP_EUNSUPPORTED, KEEP_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 PIX_F32, PIX_F16, PIX_BF16, PIX_U8_HWC = 0, 1, 2, 3
 SIM_RAW, SIM_ARGMAX, SIM_SOFTMAX, SIM_SOFTMAX_F16, SIM_TOP2SCORE = 0, 1, 2, 3, 4
-PREC_FP16, PREC_STRICT = 0, 1
+PREC_FP16, PREC_STRICT, PREC_COMP = 0, 1, 2
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "keep_profile_read": (_i32, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "keep_profile_reset": (_i32, [_vp]),
     "keep_op_linear": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "keep_op_mlp": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "keep_op_attention": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "keep_op_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "keep_op_sgemm": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp]),

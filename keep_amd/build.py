@@ -18,7 +18,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkeep_hip.so")
-SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_v3.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
+SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
+EXPERIMENT_SOURCES = ["gemm_f16_v3.hip"]      # compiled only with KEEP_BUILD_DEFINES=-DKEEP_EXPERIMENTS (measured-negative variants)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -41,11 +42,15 @@ def _sha(paths, extra="") -> str:
     return h.hexdigest()
 
 
+def _sources(defines):
+    return SOURCES + (EXPERIMENT_SOURCES if "-DKEEP_EXPERIMENTS" in defines else [])
+
+
 def _source_keys(defines):
     """One content hash per object: the source, every header and the flags (mtimes play no part: the prebuilt .so that
     travels with a snapshot has arbitrary timestamps)."""
     hdr = _sha(HEADERS, " ".join(FLAGS + list(defines)))
-    return {s: _sha([os.path.join(CSRC, s)], hdr) for s in SOURCES}
+    return {s: _sha([os.path.join(CSRC, s)], hdr) for s in _sources(defines)}
 
 
 def _read_manifest(path):
@@ -96,8 +101,9 @@ def _build(OUT: str, objdir: str, defines, verbose: bool, force: bool = False) -
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 2)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    srcs = _sources(defines)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(compile_one, srcs))
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

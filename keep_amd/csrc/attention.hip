@@ -297,12 +297,14 @@ void attention_kernel(AttnParams p) {
 
 template <int NT, bool SPLIT, int NW>
 int launch_one(const AttnParams& p, hipStream_t s) {
-    static bool attr_set = false;
     constexpr size_t bytes = att_lds_bytes(NT, SPLIT);
-    if (!attr_set) {
+    static unsigned long long done = 0;              // hipFuncSetAttribute is per device: bit d = device d opted in
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    if (dev >= 64 || !((done >> dev) & 1ull)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NT, SPLIT, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -2;
-        attr_set = true;
+        if (dev < 64) done |= 1ull << dev;
     }
     hipLaunchKernelGGL((attention_kernel<NT, SPLIT, NW>), dim3(p.batch * p.heads), dim3(NW * 64), bytes, s, p);
     return 0;
@@ -310,13 +312,15 @@ int launch_one(const AttnParams& p, hipStream_t s) {
 
 }  // namespace keepk
 
-int g_attn_waves = 8;     // wavefronts per workgroup for the unsplit 13/16-tile kernels (4 or 8)
-
-extern long long* g_gemm_dbg;
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
     using namespace keepk;
     AttnParams p = p_in;
-    p.dbg = g_gemm_dbg;
+    const int g_attn_waves = p.tune ? p.tune->attn_waves : 8;     // wavefronts per workgroup for the unsplit 13/16-tile kernels (4 or 8)
+#ifdef KEEP_DIAGNOSTICS
+    p.dbg = p.tune ? p.tune->dbg : nullptr;
+#else
+    p.dbg = nullptr;
+#endif
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
     if (p.split) {

@@ -61,6 +61,19 @@ static inline size_t blk_elems(int64_t M, int64_t K) { return (size_t)((M + 255)
 // Kernel launch parameter blocks (plain structs, passed by value)
 // ---------------------------------------------------------------------------
 
+// Kernel-selection knobs.  They belong to a handle (keep_set_option) and travel inside the launch parameter blocks:
+// there is no process-wide kernel state, so two handles (two GPUs, two threads) never see each other's settings.
+struct KeepTune {
+    int gemm_impl = 0;           // 0 auto | 128 / 256: LDS-DMA tile width (experiment builds add more)
+    int gemm_skinny_m = 320;     // calls with M <= this take the register-direct split-K kernel (0: never)
+    int gemm_splitk_tiles = 64;  // a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never)
+    int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
+    int ln_impl = 1;             // 1: LDS-transposed blk stores; 0: per-row stores
+    int attn_waves = 8;          // wavefronts per attention workgroup for 13/16-tile sequences (4 or 8)
+    int gemm_ablate = 0;         // diagnostics (KEEP_DIAGNOSTICS builds only)
+    long long* dbg = nullptr;    // diagnostics: per-workgroup shader-clock stamps
+};
+
 // Epilogue selector of the fp16 MFMA GEMM  C[m][n] = sum_k A[m][k] W[n][k].
 enum GemmEpi : int {
     EPI_F16      = 0,   // out_f16 = acc + bias                                   (QKV)
@@ -77,6 +90,12 @@ struct GemmParams {
     const f16* w_hi; const f16* w_lo;     // weights [N][K], same layout as A
     int M, N, K;                          // K = per-segment depth; multiples: N%128==0, K%64==0
     int nseg;                             // 1: A_hi*W_hi ; 3: A_hi*W_hi + A_lo*W_hi + A_hi*W_lo
+    // comp != 0: after the fp16 pass the two correction terms run on the MX-fp4 pipe (quant4.h): needs the fp4 side planes
+    // of both operands, K % 64 == 0, nseg == 1, and the 256x256 kernel (the small-M paths use nseg = 3 instead)
+    int comp;
+    const unsigned char* a_q; const unsigned char* a_sc;
+    const unsigned char* w_q; const unsigned char* w_sc;
+    unsigned char* out_q; unsigned char* out_sc;   // EPI_GELU_F16 with out_kt > 0: also emit the fp4 planes of the output (K = N of this GEMM)
     const float* bias;                    // [N]
     const float* ls;                      // [N]   (EPI_RESID_LS)
     const float* pos;                     // [197][N] (EPI_PATCH)
@@ -93,6 +112,7 @@ struct GemmParams {
     float* splitk_ws; size_t splitk_bytes; // scratch for the small-M split-K kernel (gemm_f16_skinny.hip); null: never used
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
     int ablate;                           // diagnostics only: 1 = skip staging DMA, 2 = skip MFMA loop (results wrong)
+    const KeepTune* tune;                 // kernel selection of the calling handle (null: defaults)
 };
 
 int launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);             // blk-layout operands (product path); returns GEMM_DID_LN or 0
@@ -116,6 +136,7 @@ struct AttnParams {
     int split;                            // 0/1
     float scale;                          // 1/sqrt(64)
     long long* dbg;                       // diagnostics: per-workgroup [start, staged, end] shader clocks (tools/attn_timeline.py)
+    const KeepTune* tune;
 };
 int launch_attention(const AttnParams& p, hipStream_t s);   // returns 0 or -1 (unsupported ntok)
 
@@ -128,6 +149,8 @@ struct LnParams {
     f16* out_hi; f16* out_lo;             // [rows][D] dense (nullable); blk layout when out_kt > 0
     int out_kt;
     float* out_f32; int64_t out_f32_stride;   // nullable
+    unsigned char* out_q; unsigned char* out_sc;   // nullable: fp4 side planes of the output (quant4.h), blk path only; needs out_lo semantics internally
+    const KeepTune* tune;
 };
 int launch_layernorm(const LnParams& p, hipStream_t s);
 
@@ -140,6 +163,7 @@ struct SgemmParams {
     const float* bias;                    // nullable
     int M, N, K;                          // K % 16 == 0
     float scale; int act;
+    const KeepTune* tune;
 };
 int launch_sgemm_f32(const SgemmParams& p, hipStream_t s);
 
@@ -149,6 +173,8 @@ void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_l
 void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s);
 // row-major fp32 [M][K] -> blk-layout fp16 hi (+lo); rows M..pad are zero-filled
 void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hipStream_t s);
+// the same plus the MX-fp4 side planes of quant4.h (q: both planes, sc: scales); K % 32 == 0; lo may be null
+void launch_quant_blockify(const float* src, f16* hi, f16* lo, unsigned char* q, unsigned char* sc, int M, int K, hipStream_t s);
 // blk-layout fp16 hi (+lo) -> row-major fp32 [M][K]
 void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s);
 void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s);

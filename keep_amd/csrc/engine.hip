@@ -5,6 +5,7 @@
 //   encode_image  quick_start/keep_inference.py:54-58  -> timm VisionTransformer.forward
 //   encode_text   quick_start/keep_inference.py:60-62  -> HF BertModel.forward           
 #include "common.h"
+#include "quant4.h"
 #include "../../include/keep_hip.h"
 
 #include <cstdarg>
@@ -20,16 +21,19 @@
         if (_e != hipSuccess) return (h)->fail(KEEP_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-extern int g_attn_waves;
-extern int g_ln_impl;
-extern int g_gemm_skinny_m;
-extern int g_sgemv_m;
-extern int g_gemm_splitk_tiles;
-extern int g_gemm_ablate;
-extern long long* g_gemm_dbg;
-extern int g_gemm_impl;   // gemm_f16.hip: kernel variant override (process-wide; for tests / A-B runs)
-
 namespace {
+
+// Every entry point runs on the handle's device and puts the caller's current device back (torch keeps its own notion of
+// the current device per thread; changing it behind its back redirects the caller's next allocation).
+struct DevGuard {
+    int prev = -1; bool ok = true;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define KEEP_ON_DEVICE(h) DevGuard _guard((h)->device); if (!_guard.ok) return (h)->fail(KEEP_EHIP, "hipSetDevice(%d) failed", (h)->device)
 
 struct WTensor {
     std::vector<int64_t> shape;
@@ -37,6 +41,8 @@ struct WTensor {
     float* f32 = nullptr;     // kept for vectors / embeddings / head / pooler
     f16* hi = nullptr;        // GEMM weights: fp16 planes
     f16* lo = nullptr;
+    unsigned char* q = nullptr;   // MX-fp4 side planes of (hi, lo) and their scales (quant4.h); K % 64 == 0 weights only
+    unsigned char* sc = nullptr;
 };
 
 enum Tag {
@@ -73,8 +79,12 @@ struct keep_handle {
     std::vector<BertLayer> blayers;
 
     // options
-    int precision = KEEP_PREC_FP16;
-    int strict_blocks = 0;
+    KeepTune tune;               // kernel selection (travels in the launch parameter blocks; nothing is process-wide)
+    int precision = KEEP_PREC_COMP;
+    int strict_blocks = 0;       // first n blocks / layers as full hi/lo split products (any mode)
+    int comp_full_blocks = 2;    // KEEP_PREC_COMP: first n ViT blocks run qkv / attention / proj as split products as well
+    int comp_mlp_blocks = 12;    // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
+    int comp_min_tiles = 32;     // lanes with fewer tiles take the split product where a compensated one is asked for (small-M kernels)
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
@@ -82,6 +92,7 @@ struct keep_handle {
     struct GraphSlot { hipGraphExec_t exec; unsigned long long epoch; char* arena; };
     std::map<std::string, GraphSlot> graphs;
     int use_graphs = 1;
+    unsigned long long opt_epoch = 0;   // bumped by keep_set_option / keep_finalize_weights: graphs captured under an older epoch are dropped
     hipStream_t cap_stream = nullptr;
     int dbg_calls = 0;
     int dbg_skip_ln = 0;         // diagnostics (takes effect from the 4th encode_image call, so the buffers hold real data): skip the ViT block LayerNorm launches (results wrong; bounds what fusing them away could gain)
@@ -114,8 +125,23 @@ struct keep_handle {
         err = buf;
         return code;
     }
-    bool split_layer(int i) const { return precision == KEEP_PREC_STRICT || i < strict_blocks; }
-    bool any_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
+    // Where the 11 bits of an fp16 operand are not enough (tools/precision_study.py: block 0 alone is 41 % of the cosine error
+    // variance, blocks 0-1 52 %, and outside them the MLP GEMMs carry > 80 %):
+    //   attention side (qkv, q/k/v storage, softmax probabilities, proj) of block i: split product or plain
+    //   MLP (fc1, fc2) of block i: 0 plain | 1 split (three fp16 passes) | 2 compensated (fp16 pass + two MX-fp4 correction terms)
+    bool vit_attn_split(int i) const {
+        return precision == KEEP_PREC_STRICT || i < strict_blocks || (precision == KEEP_PREC_COMP && i < comp_full_blocks);
+    }
+    int vit_mlp_mode(int i, int lane_tiles) const {
+        if (precision == KEEP_PREC_STRICT || i < strict_blocks) return 1;
+        if (precision == KEEP_PREC_COMP && i < comp_mlp_blocks) return (lane_tiles >= comp_min_tiles && vit_has_q) ? 2 : 1;
+        return 0;
+    }
+    // the text tower is 1 % of a slide's work: in the compensated mode it simply runs split products throughout
+    bool txt_split(int l) const { return precision != KEEP_PREC_FP16 || l < strict_blocks; }
+    bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
+    bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 64 == 0)
+    bool any_comp() const { return precision == KEEP_PREC_COMP && comp_mlp_blocks > 0 && vit_has_q; }
 
     bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && tag == prof_tag); }
     void prof_add_flops(int tag, double f) { if (prof_on(tag)) prof_flops[tag] += f; }
@@ -190,13 +216,16 @@ struct Carver {
 };
 
 struct VitWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo, *pat_hi, *pat_lo; float *cls, *h1;
+               unsigned char *xn_q, *xn_sc, *mlp_q, *mlp_sc;     // MX-fp4 side planes of the LayerNorm-2 output and of the MLP hidden (compensated mode)
                // compact CLS-row buffers for the last block
                float* c_resid; f16 *c_att_hi, *c_att_lo, *c_xn_hi, *c_xn_lo, *c_mlp_hi, *c_mlp_lo; };
 struct TxtWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; };
 
 size_t vit_ws_bytes(const keep_handle* h, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F, k = split ? 2 : 1;
-    return align_up(SKINNY_WS_BYTES) + align_up(M * D * 4) + k * (align_up(blk_elems(M, D) * 2) * 2 + align_up(M * 3 * D * 2) + align_up(blk_elems(M, F) * 2)) + 2 * align_up(blk_elems(Mp, 768) * 2) +
+    const size_t comp = h->any_comp() ? align_up(keepk::q4_data_bytes(M, D)) + align_up(keepk::q4_scale_bytes(M, D)) +
+                                        align_up(keepk::q4_data_bytes(M, F)) + align_up(keepk::q4_scale_bytes(M, F)) : 0;
+    return comp + align_up(SKINNY_WS_BYTES) + align_up(M * D * 4) + k * (align_up(blk_elems(M, D) * 2) * 2 + align_up(M * 3 * D * 2) + align_up(blk_elems(M, F) * 2)) + 2 * align_up(blk_elems(Mp, 768) * 2) +
            align_up((size_t)Bc * D * 4) + align_up((size_t)Bc * h->proj_dim * 4) + 4096 +
            align_up((size_t)Bc * D * 4) + 2 * (2 * align_up(blk_elems(Bc, D) * 2) + align_up(blk_elems(Bc, F) * 2));
 }
@@ -216,6 +245,10 @@ VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
     w.c_att_hi = c.take<f16>(blk_elems(Bc, D)); w.c_att_lo = c.take<f16>(blk_elems(Bc, D));
     w.c_xn_hi = c.take<f16>(blk_elems(Bc, D));  w.c_xn_lo = c.take<f16>(blk_elems(Bc, D));
     w.c_mlp_hi = c.take<f16>(blk_elems(Bc, F)); w.c_mlp_lo = c.take<f16>(blk_elems(Bc, F));
+    if (h->any_comp()) {
+        w.xn_q = c.take<unsigned char>(keepk::q4_data_bytes(M, D));  w.xn_sc = c.take<unsigned char>(keepk::q4_scale_bytes(M, D));
+        w.mlp_q = c.take<unsigned char>(keepk::q4_data_bytes(M, F)); w.mlp_sc = c.take<unsigned char>(keepk::q4_scale_bytes(M, F));
+    }
     return w;
 }
 size_t txt_ws_bytes(const keep_handle* h, int64_t Pc, int64_t T, bool split) {
@@ -250,9 +283,6 @@ int check_launch(keep_handle* h, const char* what) {
     return KEEP_OK;
 }
 
-// Bumped by every keep_set_option / keep_finalize_weights (kernel selection is partly process-wide): graphs captured
-// under an older epoch, or against an arena that has since been reallocated, are dropped and captured again.
-unsigned long long g_opt_epoch = 0;
 
 void drop_graphs(keep_handle* h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second.exec);
@@ -264,7 +294,7 @@ void drop_graphs(keep_handle* h) {
 template <class F>
 int graph_run(keep_handle* h, const std::string& key, hipStream_t s, F&& body) {
     auto it = h->graphs.find(key);
-    if (it != h->graphs.end() && (it->second.epoch != g_opt_epoch || it->second.arena != h->arena)) {
+    if (it != h->graphs.end() && (it->second.epoch != h->opt_epoch || it->second.arena != h->arena)) {
         (void)hipGraphExecDestroy(it->second.exec);
         h->graphs.erase(it);
         it = h->graphs.end();
@@ -281,14 +311,14 @@ int graph_run(keep_handle* h, const std::string& key, hipStream_t s, F&& body) {
         const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         HIPCHK(h, ei);
-        it = h->graphs.emplace(key, keep_handle::GraphSlot{ex, g_opt_epoch, h->arena}).first;
+        it = h->graphs.emplace(key, keep_handle::GraphSlot{ex, h->opt_epoch, h->arena}).first;
     }
     HIPCHK(h, hipGraphLaunch(it->second.exec, s));
     return KEEP_OK;
 }
 
 int run_gemm(keep_handle* h, int tag, GemmParams p, int epi, hipStream_t s, float* splitk) {
-    h->prof_add_flops(tag, 2.0 * p.M * (double)p.N * p.K * p.nseg);
+    h->prof_add_flops(tag, 2.0 * p.M * (double)p.N * p.K);     // algorithmic FLOPs: extra passes of a split / compensated product are not counted
     p.splitk_ws = splitk; p.splitk_bytes = SKINNY_WS_BYTES;
     return launch_gemm_f16(p, epi, s);
 }
@@ -299,8 +329,9 @@ void offer_ln(GemmParams& p, const LnParams& ln) {
     p.ln_out_hi = ln.out_hi; p.ln_out_lo = ln.out_lo; p.ln_out_f32 = ln.out_f32;
 }
 
-GemmParams gemm_params(const f16* a_hi, const f16* a_lo, const WTensor* w, int M, bool split, const float* bias) {
+GemmParams gemm_params(const keep_handle* h, const f16* a_hi, const f16* a_lo, const WTensor* w, int M, bool split, const float* bias) {
     GemmParams p{};
+    p.tune = &h->tune;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w->hi; p.w_lo = w->lo;
     p.M = M; p.N = (int)w->shape[0]; p.K = (int)(w->numel / w->shape[0]);
     p.nseg = split ? 3 : 1;
@@ -332,7 +363,7 @@ int vit_begin(keep_handle* h, VitLane& L) {
     }
     {
         Scope sc(h, T_VIT_PATCH, s);
-        GemmParams p = gemm_params(ws.pat_hi, ws.pat_lo, find(h, "visual.patch_embed.proj.weight"), Bc * 196, sp0,
+        GemmParams p = gemm_params(h, ws.pat_hi, ws.pat_lo, find(h, "visual.patch_embed.proj.weight"), Bc * 196, sp0,
                                    find(h, "visual.patch_embed.proj.bias")->f32);
         p.pos = find(h, "visual.pos_embed")->f32;
         p.resid = ws.resid;
@@ -345,86 +376,102 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     const int D = h->vit_D, Bc = L.Bc, M = Bc * 197;
     hipStream_t s = L.s; VitWs& ws = L.ws;
     auto mark = [&](int stage) { if (i == 0 && L.skew_ev && L.skew_stage == stage) (void)hipEventRecord(L.skew_ev, s); };
-    {
-        const VitBlock& b = h->vblocks[i];
-        const bool sp = h->split_layer(i);
-        LnParams ln{};
-        ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
-        ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr; ln.out_kt = D / 32;
-        if (!L.xn_ready && !(h->dbg_skip_ln && h->dbg_calls > 3)) {
-            Scope sc(h, T_VIT_LN, s);
-            ln.gamma = b.n1w; ln.beta = b.n1b;
-            if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
-        }
-        L.xn_ready = false;
-        {
-            Scope sc(h, T_VIT_QKV, s);
-            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
-            p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-            run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk);
-        }
-        mark(1);
-        // Last block: everything after the attention is per-token and only the CLS token is pooled
-        // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
-        // Exact (same arithmetic on the rows that matter); the skipped FLOPs still count as algorithmic work.
-        const bool cls_only = (i == h->vit_depth - 1) && h->cls_tail;
-        {
-            Scope sc(h, T_VIT_ATTN, s);
-            AttnParams a{};
-            a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
-            a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
-            a.q_rows = cls_only ? 1 : 0;
-            if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
-        }
-        mark(2);
-        const int Mr = cls_only ? Bc : M;
-        float* resid = cls_only ? ws.c_resid : ws.resid;
-        const f16 *att_hi = ws.att_hi, *att_lo = ws.att_lo;
-        f16 *xn_hi = ws.xn_hi, *xn_lo = ws.xn_lo, *mlp_hi = ws.mlp_hi, *mlp_lo = ws.mlp_lo;
-        if (cls_only) {
-            Scope sc(h, T_VIT_HEAD, s);
-            launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
-            launch_gather_rows_blk(ws.att_hi, 197, ws.c_att_hi, Bc, D, s);
-            if (sp) launch_gather_rows_blk(ws.att_lo, 197, ws.c_att_lo, Bc, D, s);
-            att_hi = ws.c_att_hi; att_lo = ws.c_att_lo; xn_hi = ws.c_xn_hi; xn_lo = ws.c_xn_lo; mlp_hi = ws.c_mlp_hi; mlp_lo = ws.c_mlp_lo;
-            L.cls_compact = true;
-        }
-        ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = sp ? xn_lo : nullptr;
-        ln.gamma = b.n2w; ln.beta = b.n2b;
-        int did;
-        {
-            Scope sc(h, T_VIT_PROJ, s);
-            GemmParams p = gemm_params(att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
-            p.ls = b.ls1; p.resid = resid;
-            offer_ln(p, ln);
-            did = run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
-        }
-        mark(3);
-        if (!(did & GEMM_DID_LN) && !(h->dbg_skip_ln && h->dbg_calls > 3)) {
-            Scope sc(h, T_VIT_LN, s);
-            launch_layernorm(ln, s);
-        }
-        {
-            Scope sc(h, T_VIT_FC1, s);
-            GemmParams p = gemm_params(xn_hi, xn_lo, b.fc1, Mr, sp, b.fc1_b);
-            p.out_hi = mlp_hi; p.out_lo = sp ? mlp_lo : nullptr; p.out_kt = h->vit_F / 32;
-            run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s, ws.splitk);
-        }
-        mark(4);
-        {
-            Scope sc(h, T_VIT_FC2, s);
-            GemmParams p = gemm_params(mlp_hi, mlp_lo, b.fc2, Mr, sp, b.fc2_b);
-            p.ls = b.ls2; p.resid = resid;
-            if (i + 1 < h->vit_depth && !cls_only) {        // next block's LayerNorm-1 reads exactly the rows written here
-                const VitBlock& nb = h->vblocks[i + 1];
-                ln.x = ws.resid; ln.rows = M; ln.out_hi = ws.xn_hi; ln.out_lo = h->split_layer(i + 1) ? ws.xn_lo : nullptr;
-                ln.gamma = nb.n1w; ln.beta = nb.n1b;
-                offer_ln(p, ln);
-            }
-            L.xn_ready = (run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk) & GEMM_DID_LN) != 0;
-        }
-        mark(5);
+    const VitBlock& b = h->vblocks[i];
+    // Last block: everything after the attention is per-token and only the CLS token is pooled
+    // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
+    // Exact (same arithmetic on the rows that matter); the skipped FLOPs still count as algorithmic work.
+    const bool cls_only = (i == h->vit_depth - 1) && h->cls_tail;
+    const bool sp = h->vit_attn_split(i);                              // qkv / attention / proj as split products
+    const int mlp = h->vit_mlp_mode(i, cls_only ? 0 : Bc);             // fc1 / fc2: 0 plain, 1 split, 2 compensated (MX-fp4 corrections)
+    const bool mlp_lo = mlp == 1, mlp_q = mlp == 2;
+#ifdef KEEP_DIAGNOSTICS
+    const bool skip_ln = h->dbg_skip_ln && h->dbg_calls > 3;
+#else
+    const bool skip_ln = false;
+#endif
+    LnParams ln{};
+    ln.tune = &h->tune;
+    ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
+    ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr; ln.out_kt = D / 32;
+    if (!L.xn_ready && !skip_ln) {
+        Scope sc(h, T_VIT_LN, s);
+        ln.gamma = b.n1w; ln.beta = b.n1b;
+        if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
     }
+    L.xn_ready = false;
+    {
+        Scope sc(h, T_VIT_QKV, s);
+        GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
+        p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
+        run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk);
+    }
+    mark(1);
+    {
+        Scope sc(h, T_VIT_ATTN, s);
+        AttnParams a{};
+        a.tune = &h->tune;
+        a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
+        a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
+        a.q_rows = cls_only ? 1 : 0;
+        if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
+    }
+    mark(2);
+    const int Mr = cls_only ? Bc : M;
+    float* resid = cls_only ? ws.c_resid : ws.resid;
+    const f16 *att_hi = ws.att_hi, *att_lo = ws.att_lo;
+    f16 *xn_hi = ws.xn_hi, *xn_lo = ws.xn_lo, *mlp_hi = ws.mlp_hi, *mlp_lo_p = ws.mlp_lo;
+    if (cls_only) {
+        Scope sc(h, T_VIT_HEAD, s);
+        launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
+        launch_gather_rows_blk(ws.att_hi, 197, ws.c_att_hi, Bc, D, s);
+        if (sp) launch_gather_rows_blk(ws.att_lo, 197, ws.c_att_lo, Bc, D, s);
+        att_hi = ws.c_att_hi; att_lo = ws.c_att_lo; xn_hi = ws.c_xn_hi; xn_lo = ws.c_xn_lo; mlp_hi = ws.c_mlp_hi; mlp_lo_p = ws.c_mlp_lo;
+        L.cls_compact = true;
+    }
+    ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = mlp_lo ? xn_lo : nullptr;
+    ln.out_q = mlp_q ? ws.xn_q : nullptr; ln.out_sc = mlp_q ? ws.xn_sc : nullptr;
+    ln.gamma = b.n2w; ln.beta = b.n2b;
+    int did;
+    {
+        Scope sc(h, T_VIT_PROJ, s);
+        GemmParams p = gemm_params(h, att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
+        p.ls = b.ls1; p.resid = resid;
+        if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
+        did = run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
+    }
+    mark(3);
+    if (!(did & GEMM_DID_LN) && !skip_ln) {
+        Scope sc(h, T_VIT_LN, s);
+        if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
+    }
+    {
+        Scope sc(h, T_VIT_FC1, s);
+        GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, b.fc1_b);
+        p.out_hi = mlp_hi; p.out_lo = mlp_lo ? mlp_lo_p : nullptr; p.out_kt = h->vit_F / 32;
+        if (mlp_q) {
+            p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
+            p.out_q = ws.mlp_q; p.out_sc = ws.mlp_sc;
+        }
+        if (run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "compensated fc1 launch failed");
+    }
+    mark(4);
+    {
+        Scope sc(h, T_VIT_FC2, s);
+        GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, b.fc2_b);
+        p.ls = b.ls2; p.resid = resid;
+        if (mlp_q) { p.comp = 1; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
+        if (i + 1 < h->vit_depth && !cls_only) {        // next block's LayerNorm-1 reads exactly the rows written here
+            const VitBlock& nb = h->vblocks[i + 1];
+            ln.x = ws.resid; ln.rows = M; ln.out_hi = ws.xn_hi; ln.out_lo = h->vit_attn_split(i + 1) ? ws.xn_lo : nullptr;
+            ln.out_q = nullptr; ln.out_sc = nullptr;
+            ln.gamma = nb.n1w; ln.beta = nb.n1b;
+            offer_ln(p, ln);
+        }
+        const int rc = run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk);
+        if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "compensated fc2 launch failed");
+        L.xn_ready = (rc & GEMM_DID_LN) != 0;
+    }
+    mark(5);
     return KEEP_OK;
 }
 
@@ -435,6 +482,7 @@ int vit_end(keep_handle* h, VitLane& L) {
         // final LayerNorm is per-token, global_pool='token' reads row 0 only -> normalise CLS rows only
         Scope sc(h, T_VIT_HEAD, s);
         LnParams ln{};
+        ln.tune = &h->tune;
         ln.x = L.cls_compact ? ws.c_resid : ws.resid; ln.x_stride = L.cls_compact ? (int64_t)D : (int64_t)197 * D;
         ln.rows = Bc; ln.D = D; ln.eps = 1e-6f;
         ln.gamma = find(h, "visual.norm.weight")->f32; ln.beta = find(h, "visual.norm.bias")->f32;
@@ -443,6 +491,7 @@ int vit_end(keep_handle* h, VitLane& L) {
         const WTensor* w0 = find(h, "visual_head.0.weight");
         const WTensor* w2 = find(h, "visual_head.2.weight");
         SgemmParams g{};
+        g.tune = &h->tune;
         g.a = ws.cls; g.lda = D; g.b = w0->f32; g.ldb = D; g.out = ws.h1; g.ldo = h->proj_dim;
         g.bias = find(h, "visual_head.0.bias")->f32; g.M = Bc; g.N = h->proj_dim; g.K = D; g.scale = 1.f; g.act = ACT_GELU;
         if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "visual_head.0 shape");
@@ -470,30 +519,32 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
     }
     for (int l = 0; l < h->bert_layers; ++l) {
         const BertLayer& b = h->blayers[l];
-        const bool sp = h->split_layer(l);
-        const bool sp_next = (l + 1 < h->bert_layers) && h->split_layer(l + 1);
+        const bool sp = h->txt_split(l);
+        const bool sp_next = (l + 1 < h->bert_layers) && h->txt_split(l + 1);
         {
             Scope sc(h, T_TXT_QKV, s);
-            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
+            GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
             run_gemm(h, T_TXT_QKV, p, EPI_F16, s, ws.splitk);
         }
         {
             Scope sc(h, T_TXT_ATTN, s);
             AttnParams a{};
+            a.tune = &h->tune;
             a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
             a.mask = mask; a.batch = Pc; a.ntok = T; a.heads = h->bert_heads; a.split = sp; a.scale = 0.125f; a.out_kt = H / 32;
             if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %d unsupported%s", T,
                                                        sp ? " in strict mode (max 256)" : " (max 512)");
         }
         LnParams ln{};
+        ln.tune = &h->tune;
         ln.x = ws.resid; ln.x_stride = H; ln.rows = M; ln.D = H; ln.eps = 1e-12f;
         ln.out_f32 = ws.resid; ln.out_f32_stride = H; ln.out_hi = ws.xn_hi; ln.out_kt = H / 32;
         ln.gamma = b.ln1w; ln.beta = b.ln1b; ln.out_lo = sp ? ws.xn_lo : nullptr;
         int did;
         {
             Scope sc(h, T_TXT_OUT, s);
-            GemmParams p = gemm_params(ws.att_hi, ws.att_lo, b.o, M, sp, b.o_b);
+            GemmParams p = gemm_params(h, ws.att_hi, ws.att_lo, b.o, M, sp, b.o_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
             offer_ln(p, ln);
             did = run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s, ws.splitk);
@@ -504,14 +555,14 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
         }
         {
             Scope sc(h, T_TXT_FFN1, s);
-            GemmParams p = gemm_params(ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
+            GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
             p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->bert_F / 32;
             run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s, ws.splitk);
         }
         ln.gamma = b.ln2w; ln.beta = b.ln2b; ln.out_lo = sp_next ? ws.xn_lo : nullptr;
         {
             Scope sc(h, T_TXT_FFN2, s);
-            GemmParams p = gemm_params(ws.mlp_hi, ws.mlp_lo, b.d, M, sp, b.d_b);
+            GemmParams p = gemm_params(h, ws.mlp_hi, ws.mlp_lo, b.d, M, sp, b.d_b);
             p.resid = ws.resid; p.out_f32 = ws.resid;
             offer_ln(p, ln);
             did = run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s, ws.splitk);
@@ -524,6 +575,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
     {
         Scope sc(h, T_TXT_POOL, s);
         SgemmParams g{};
+        g.tune = &h->tune;
         g.a = ws.resid; g.lda = (int64_t)T * H;            // row p*T: the [CLS] token of prompt p
         g.b = find(h, "text.pooler.dense.weight")->f32; g.ldb = H; g.out = out; g.ldo = H;
         g.bias = find(h, "text.pooler.dense.bias")->f32; g.M = Pc; g.N = H; g.K = H; g.scale = 1.f; g.act = ACT_TANH;
@@ -543,7 +595,14 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         if (n % 256 || k % 32) return h->fail(KEEP_EUNSUPPORTED, "%s: [%lld,%lld] is not tileable (rows %% 256, cols %% 32)", key.c_str(), (long long)n, (long long)k);
         HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
         HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
-        launch_split_blockify(dev, t.hi, t.lo, (int)n, (int)k, nullptr);
+        // the MLP weights of the image tower also get the MX-fp4 side planes of the compensated product (quant4.h)
+        if (key.find(".mlp.fc") != std::string::npos && starts_with(key, "visual.") && k % 64 == 0) {
+            HIPCHK(h, hipMalloc(&t.q, keepk::q4_data_bytes(n, k)));
+            HIPCHK(h, hipMalloc(&t.sc, keepk::q4_scale_bytes(n, k)));
+            launch_quant_blockify(dev, t.hi, t.lo, t.q, t.sc, (int)n, (int)k, nullptr);
+        } else {
+            launch_split_blockify(dev, t.hi, t.lo, (int)n, (int)k, nullptr);
+        }
         HIPCHK(h, hipStreamSynchronize(nullptr));
     } else {
         const size_t bytes = (size_t)(t.numel > 4 ? t.numel : 4) * sizeof(float);
@@ -555,6 +614,8 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         if (it->second.f32) hipFree(it->second.f32);
         if (it->second.hi) hipFree(it->second.hi);
         if (it->second.lo) hipFree(it->second.lo);
+        if (it->second.q) hipFree(it->second.q);
+        if (it->second.sc) hipFree(it->second.sc);
     }
     h->w[key] = t;
     h->finalized = false;
@@ -617,6 +678,8 @@ int finalize_vit(keep_handle* h) {
     }
     if (!miss.empty()) return h->fail(KEEP_EKEY, "missing or mis-shaped key(s): %s", miss.c_str());
     if (F % 256 || D % 256 || PJ % 16) return h->fail(KEEP_EUNSUPPORTED, "ViT dims not tileable");
+    h->vit_has_q = true;
+    for (auto& b : h->vblocks) if (!b.fc1->q || !b.fc2->q) h->vit_has_q = false;
     h->vit_depth = depth; h->vit_D = (int)D; h->vit_heads = (int)(D / 64); h->vit_F = (int)F; h->proj_dim = (int)PJ;
     return KEEP_OK;
 }
@@ -747,7 +810,8 @@ int keep_create(int device_id, keep_handle** out) {
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return KEEP_EHIP;
-    if (hipSetDevice(device_id) != hipSuccess) return KEEP_EHIP;
+    DevGuard guard(device_id);
+    if (!guard.ok) return KEEP_EHIP;
     keep_handle* h = new keep_handle();
     h->device = device_id;
     if (hipMalloc(&h->err_flag, sizeof(int)) != hipSuccess) { delete h; return KEEP_ENOMEM; }
@@ -758,11 +822,13 @@ int keep_create(int device_id, keep_handle** out) {
 
 int keep_destroy(keep_handle* h) {
     if (!h) return KEEP_OK;
-    hipSetDevice(h->device);
+    DevGuard guard(h->device);
     hipDeviceSynchronize();
     h->prof_collect();
     for (auto& e : h->pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo); }
+    for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo);
+                            if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); }
+    if (h->tune.dbg) hipFree(h->tune.dbg);
     for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
     drop_graphs(h);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
@@ -778,7 +844,7 @@ const char* keep_last_error(keep_handle* h) { return h ? h->err.c_str() : "null 
 
 int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndim, const int64_t* shape, int on_device) {
     if (!h || !key || !data || ndim < 0 || ndim > 8) return KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     const std::string k(key);
     if (k == "text.embeddings.position_ids" || k == "text.embeddings.token_type_ids") return KEEP_OK;   // buffers of older checkpoints
     if (!known_key(k)) return h->fail(KEEP_EKEY, "unexpected key %s", key);
@@ -786,7 +852,12 @@ int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndi
     if (ndim == 0) shp = {1};
     const int64_t n = numel_of(shp);
     if (n <= 0) return h->fail(KEEP_EINVAL, "%s: bad shape", key);
-    if (on_device) return store_tensor(h, k, data, shp);
+    if (on_device) {
+        // the repack below runs on the null stream; whatever produced `data` (e.g. a dtype conversion on the caller's
+        // stream) must have finished first, and this entry point takes no stream: load time, so simply drain the device
+        HIPCHK(h, hipDeviceSynchronize());
+        return store_tensor(h, k, data, shp);
+    }
     float* tmp = nullptr;
     HIPCHK(h, hipMalloc(&tmp, n * sizeof(float)));
     hipError_t e = hipMemcpy(tmp, data, n * sizeof(float), hipMemcpyHostToDevice);
@@ -797,8 +868,8 @@ int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndi
 
 int keep_finalize_weights(keep_handle* h) {
     if (!h) return KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
-    ++g_opt_epoch;
+    KEEP_ON_DEVICE(h);
+    ++h->opt_epoch;
     int rc = finalize_vit(h);
     if (rc) return rc;
     rc = finalize_bert(h);
@@ -816,47 +887,65 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     if (!h || !name) return KEEP_EINVAL;
     const std::string n(name);
     const int v = (int)value;
-    ++g_opt_epoch;
+    ++h->opt_epoch;               // captured graphs bake kernel selection and precision in: drop them lazily
+    KeepTune& t = h->tune;
     if (n == "graphs") { h->use_graphs = v ? 1 : 0; return KEEP_OK; }
-    if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
+    if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT && v != KEEP_PREC_COMP) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
+    else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
+    else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
+    else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
-    else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); g_gemm_splitk_tiles = v; }
-    else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); g_sgemv_m = v; }
-    else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); g_gemm_skinny_m = v; }
-    else if (n == "dbg_skip_ln") h->dbg_skip_ln = v;
+    else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
+    else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); t.sgemv_m = v; }
+    else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); t.gemm_skinny_m = v; }
     else if (n == "lane_min_tiles") { if (v < 6) return h->fail(KEEP_EINVAL, "lane_min_tiles must be >= 6"); h->lane_min_tiles = v; }
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
-    else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); g_ln_impl = v; }
-    else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); g_attn_waves = v; }
-    else if (n == "gemm_ablate") { g_gemm_ablate = v; }
-    else if (n == "gemm_dbg") {
-        if (v && !g_gemm_dbg) { HIPCHK(h, hipMalloc(&g_gemm_dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(g_gemm_dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
-        if (!v && g_gemm_dbg) { hipFree(g_gemm_dbg); g_gemm_dbg = nullptr; }
+    else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); t.ln_impl = v; }
+    else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); t.attn_waves = v; }
+    else if (n == "gemm_impl") {
+        bool ok = v == 0 || v == 128 || v == 256;
+#ifdef KEEP_EXPERIMENTS
+        ok = ok || v == 1 || v == 3 || v == 2128 || v == 3256 || v == 4256;
+#endif
+        if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256; experiment builds add 1, 3, 2128, 3256, 4256)", v);
+        t.gemm_impl = v;
     }
-    else if (n == "gemm_impl") { if (v != 0 && v != 1 && v != 3 && v != 128 && v != 256 && v != 2128 && v != 3256 && v != 4256) return h->fail(KEEP_EINVAL, "gemm_impl %d", v); g_gemm_impl = v; }
+#ifdef KEEP_DIAGNOSTICS
+    // result-changing / timing diagnostics exist only in -DKEEP_DIAGNOSTICS builds (tools/gemm_timeline.py, tools/attn_timeline.py)
+    else if (n == "dbg_skip_ln") h->dbg_skip_ln = v;
+    else if (n == "gemm_ablate") { t.gemm_ablate = v; }
+    else if (n == "gemm_dbg") {
+        if (v && !t.dbg) { HIPCHK(h, hipMalloc(&t.dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(t.dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
+        if (!v && t.dbg) { hipFree(t.dbg); t.dbg = nullptr; }
+    }
+#endif
     else return h->fail(KEEP_EINVAL, "unknown option %s", name);
     return KEEP_OK;
 }
 double keep_get_option(keep_handle* h, const char* name) {
     if (!h || !name) return -1;
     const std::string n(name);
+    const KeepTune& t = h->tune;
     if (n == "precision") return h->precision;
     if (n == "strict_blocks") return h->strict_blocks;
+    if (n == "comp_full_blocks") return h->comp_full_blocks;
+    if (n == "comp_mlp_blocks") return h->comp_mlp_blocks;
+    if (n == "comp_min_tiles") return h->comp_min_tiles;
     if (n == "max_tiles") return h->max_tiles;
     if (n == "max_prompts") return h->max_prompts;
-    if (n == "gemm_impl") return g_gemm_impl;
+    if (n == "gemm_impl") return t.gemm_impl;
     if (n == "streams") return h->n_streams;
     if (n == "graphs") return h->use_graphs;
-    if (n == "gemm_skinny_m") return g_gemm_skinny_m;
-    if (n == "sgemv_m") return g_sgemv_m;
-    if (n == "gemm_splitk_tiles") return g_gemm_splitk_tiles;
-    if (n == "ln_impl") return g_ln_impl;
-    if (n == "attn_waves") return g_attn_waves;
+    if (n == "gemm_skinny_m") return t.gemm_skinny_m;
+    if (n == "sgemv_m") return t.sgemv_m;
+    if (n == "gemm_splitk_tiles") return t.gemm_splitk_tiles;
+    if (n == "ln_impl") return t.ln_impl;
+    if (n == "attn_waves") return t.attn_waves;
     if (n == "lane_skew") return h->lane_skew;
     if (n == "lane0_permille") return h->lane0_permille;
     if (n == "cls_tail") return h->cls_tail;
@@ -865,7 +954,7 @@ double keep_get_option(keep_handle* h, const char* name) {
 
 int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
     if (!h || !h->finalized) return h ? h->fail(KEEP_ESTATE, "weights not finalised") : KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     size_t need = 0;
     if (tiles > 0 && h->vit_depth) {
         int lanes = h->n_streams;
@@ -893,7 +982,7 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
     if (!pixels || !out || B < 0) return h->fail(KEEP_EINVAL, "null pointer or negative batch");
     if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_U8_HWC) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
     if (B == 0) return KEEP_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     ++h->dbg_calls;
     if (h->use_graphs && !h->prof_mode && B * 197 <= SKINNY_MAX_M && B <= h->max_tiles) {
@@ -988,7 +1077,7 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     if (T > h->bert_maxpos) return h->fail(KEEP_EINVAL, "sequence length %lld exceeds max_position_embeddings %d", (long long)T, h->bert_maxpos);
     if (T > 512 || (h->any_split() && T > 256)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
     if (P == 0) return KEEP_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const int64_t pc_max = P < h->max_prompts ? P : h->max_prompts;
     const size_t ws_bytes = align_up(txt_ws_bytes(h, pc_max, T, h->any_split()));
@@ -1030,7 +1119,7 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
 
 int keep_token_error(keep_handle* h, void* stream) {
     if (!h) return KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     int flag = 0;
     HIPCHK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
@@ -1045,10 +1134,10 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
     if (mode == KEEP_SIM_ARGMAX && !argmax_out) return h->fail(KEEP_EINVAL, "argmax_out is null");
     if (mode != KEEP_SIM_ARGMAX && !out) return h->fail(KEEP_EINVAL, "out is null");
     if (N == 0) return KEEP_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     Scope sc(h, T_SIM, s);
-    if (g_sgemv_m > 0 && launch_sim_small(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
+    if (h->tune.sgemv_m > 0 && launch_sim_small(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
         return check_launch(h, "similarity");
     float* logits = (float*)out;
     const bool need_tmp = (mode == KEEP_SIM_ARGMAX && !out) || mode == KEEP_SIM_SOFTMAX_F16 || mode == KEEP_SIM_TOP2SCORE;
@@ -1062,6 +1151,7 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
         logits = (float*)h->arena;
     }
     SgemmParams g{};
+    g.tune = &h->tune;
     g.a = img; g.lda = D; g.b = txt; g.ldb = D; g.out = logits; g.ldo = P; g.bias = nullptr;
     g.M = (int)N; g.N = (int)P; g.K = (int)D; g.act = ACT_NONE;
     g.scale = (mode == KEEP_SIM_RAW || mode == KEEP_SIM_ARGMAX) ? scale : 1.0f;
@@ -1080,7 +1170,7 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
                        float* scores_out, void* stream) {
     if (!h) return KEEP_EINVAL;
     if (!feats || !bank || !scores_out || N < 1 || K < 1 || C < 2 || D < 16 || D % 16) return h->fail(KEEP_EINVAL, "bad prompt_scores arguments");
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     Scope sc(h, T_SIM, s);
     const int64_t KC = K * C;
@@ -1098,6 +1188,7 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t n = (N - r0) < chunk ? (N - r0) : chunk;
         SgemmParams g{};
+        g.tune = &h->tune;
         g.a = feats + r0 * D; g.lda = D; g.b = bank; g.ldb = D; g.out = logits; g.ldo = KC; g.bias = nullptr;
         g.M = (int)n; g.N = (int)KC; g.K = (int)D; g.scale = 1.0f; g.act = ACT_NONE;
         if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "prompt_scores shape");
@@ -1111,7 +1202,7 @@ int keep_group_argmax(keep_handle* h, const float* feats, const float* bank, int
                       int32_t* labels_out, void* stream) {
     if (!h) return KEEP_EINVAL;
     if (!feats || !bank || !labels_out || N < 1 || K < 1 || C < 1 || D < 16 || D % 16) return h->fail(KEEP_EINVAL, "bad group_argmax arguments");
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     Scope sc(h, T_SIM, s);
     const int64_t KC = K * C;
@@ -1124,6 +1215,7 @@ int keep_group_argmax(keep_handle* h, const float* feats, const float* bank, int
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t n = (N - r0) < chunk ? (N - r0) : chunk;
         SgemmParams g{};
+        g.tune = &h->tune;
         g.a = feats + r0 * D; g.lda = D; g.b = bank; g.ldb = D; g.out = logits; g.ldo = KC; g.bias = nullptr;
         g.M = (int)n; g.N = (int)KC; g.K = (int)D; g.scale = 1.0f; g.act = ACT_NONE;
         if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "group_argmax shape");
@@ -1137,7 +1229,7 @@ int keep_retrieval_rank(keep_handle* h, const float* txt, const float* img, int6
                         const int32_t* target, int32_t* rank_out, void* stream) {
     if (!h) return KEEP_EINVAL;
     if (!txt || !img || !rank_out || P < 1 || N < 1 || D < 16 || D % 16 || (!target && P > N)) return h->fail(KEEP_EINVAL, "bad retrieval_rank arguments");
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     Scope sc(h, T_SIM, s);
     int64_t chunk = ((int64_t)256 << 20) / (N * 4);
@@ -1149,6 +1241,7 @@ int keep_retrieval_rank(keep_handle* h, const float* txt, const float* img, int6
     for (int64_t r0 = 0; r0 < P; r0 += chunk) {
         const int64_t n = (P - r0) < chunk ? (P - r0) : chunk;
         SgemmParams g{};
+        g.tune = &h->tune;
         g.a = txt + r0 * D; g.lda = D; g.b = img; g.ldb = D; g.out = sim; g.ldo = N; g.bias = nullptr;
         g.M = (int)n; g.N = (int)N; g.K = (int)D; g.scale = 1.0f; g.act = ACT_NONE;
         if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "retrieval_rank shape");
@@ -1161,7 +1254,7 @@ int keep_refine(keep_handle* h, const float* probs, const int64_t* coords, int64
                 float* out_mean, int32_t* is_first, void* stream) {
     if (!h) return KEEP_EINVAL;
     if (!probs || !coords || !out_mean || !is_first || N < 1 || C < 1 || N > (1 << 29)) return h->fail(KEEP_EINVAL, "bad refine arguments");
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     unsigned size = 1024;
     while ((int64_t)size < 2 * N) size <<= 1;
@@ -1186,7 +1279,7 @@ int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t
     if (!h || !tag) return KEEP_EINVAL;
     const int t = tag_by_name(tag);
     if (t < 0) return h->fail(KEEP_EINVAL, "unknown profile tag %s", tag);
-    hipSetDevice(h->device);
+    DevGuard guard(h->device);
     h->prof_collect();
     if (total_ms) *total_ms = h->prof_ms[t];
     if (launches) *launches = h->prof_n[t];
@@ -1195,7 +1288,7 @@ int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t
 }
 int keep_profile_reset(keep_handle* h) {
     if (!h) return KEEP_EINVAL;
-    hipSetDevice(h->device);
+    DevGuard guard(h->device);
     h->prof_collect();
     for (int i = 0; i < T_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; h->prof_flops[i] = 0; }
     return KEEP_OK;
@@ -1205,11 +1298,11 @@ int keep_profile_reset(keep_handle* h) {
 int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls, const float* resid,
                    int64_t M, int64_t N, int64_t K, int epi, int split, float* out, void* stream) {
     if (!h || !a || !w || !bias || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
-    const bool rowmajor = (g_gemm_impl == 1);      // cross-check variant: 128x128 register-staged kernel on row-major operands
+    const bool rowmajor = (h->tune.gemm_impl == 1);      // cross-check variant: 128x128 register-staged kernel on row-major operands
     if (M < 1 || N % 128 || N < 128 || K < 64 || K % (rowmajor ? 64 : 32)) return h->fail(KEEP_EUNSUPPORTED, "linear needs N%%128==0 and K%%32==0 (K%%64 for gemm_impl=1)");
     if (epi != EPI_F16 && epi != EPI_GELU_F16 && epi != EPI_RESID_LS && epi != EPI_RESID_F32) return h->fail(KEEP_EINVAL, "epilogue %d", epi);
     if ((epi == EPI_RESID_LS && (!ls || !resid)) || (epi == EPI_RESID_F32 && !resid)) return h->fail(KEEP_EINVAL, "missing ls/resid");
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     Tmp t;
     const size_t ae = blk_elems(M, K), we = blk_elems(N, K), oe = blk_elems(M, N);
@@ -1217,16 +1310,28 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     f16* w_hi = t.get<f16>(we); f16* w_lo = t.get<f16>(we);
     f16* o_hi = t.get<f16>(oe); f16* o_lo = t.get<f16>(oe);
     if (!a_hi || !a_lo || !w_hi || !w_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
-    if (rowmajor) { launch_split_f16(a, a_hi, a_lo, M * K, s); launch_split_f16(w, w_hi, w_lo, N * K, s); }
+    const bool comp = split == 2;
+    unsigned char *a_q = nullptr, *a_sc = nullptr, *w_q = nullptr, *w_sc = nullptr;
+    if (comp) {
+        if (rowmajor || N % 256 || K % 64 || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%64==0 and epilogue 0/1/2");
+        a_q = t.get<unsigned char>(keepk::q4_data_bytes(M, K)); a_sc = t.get<unsigned char>(keepk::q4_scale_bytes(M, K));
+        w_q = t.get<unsigned char>(keepk::q4_data_bytes(N, K)); w_sc = t.get<unsigned char>(keepk::q4_scale_bytes(N, K));
+        if (!a_q || !a_sc || !w_q || !w_sc) return h->fail(KEEP_ENOMEM, "temp alloc");
+        launch_quant_blockify(a, a_hi, a_lo, a_q, a_sc, (int)M, (int)K, s); launch_quant_blockify(w, w_hi, w_lo, w_q, w_sc, (int)N, (int)K, s);
+    }
+    else if (rowmajor) { launch_split_f16(a, a_hi, a_lo, M * K, s); launch_split_f16(w, w_hi, w_lo, N * K, s); }
     else { launch_split_blockify(a, a_hi, a_lo, (int)M, (int)K, s); launch_split_blockify(w, w_hi, w_lo, (int)N, (int)K, s); }
     GemmParams p{};
+    p.tune = &h->tune;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
-    p.nseg = split ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
+    p.nseg = (split == 1) ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
+    if (comp) { p.comp = 1; p.a_q = a_q; p.a_sc = a_sc; p.w_q = w_q; p.w_sc = w_sc; }
     if (!rowmajor) {                               // auto mode may take a split-K path (small or mid-size M), as the towers do
         p.splitk_ws = t.get<float>(SKINNY_WS_BYTES / 4); p.splitk_bytes = SKINNY_WS_BYTES;
         if (!p.splitk_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
     }
-    auto launch = [&](const GemmParams& q) { if (rowmajor) launch_gemm_f16_rowmajor(q, epi, s); else launch_gemm_f16(q, epi, s); };
+    int launch_rc = 0;
+    auto launch = [&](const GemmParams& q) { if (rowmajor) launch_gemm_f16_rowmajor(q, epi, s); else launch_rc = launch_gemm_f16(q, epi, s); };
     if (epi == EPI_F16 || epi == EPI_GELU_F16) {
         p.out_hi = o_hi; p.out_lo = split ? o_lo : nullptr;
         // as in the towers: the GELU output feeds another GEMM (blk layout), the plain one feeds attention (row-major)
@@ -1243,13 +1348,54 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
         launch(p);
     }
     HIPCHK(h, hipStreamSynchronize(s));
+    if (launch_rc < 0) return h->fail(KEEP_EUNSUPPORTED, "op_linear: no kernel for this shape / mode");
     return check_launch(h, "op_linear");
+}
+
+int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* ln_b, const float* fc1_w, const float* fc1_b,
+                const float* fc2_w, const float* fc2_b, const float* ls, int64_t M, int64_t D, int64_t F, int mode, float* out, void* stream) {
+    if (!h || !x || !ln_w || !ln_b || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !ls || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
+    if (M < 1 || (D != 768 && D != 1024) || F % 256 || F < 256 || mode < 0 || mode > 2) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: D in {768, 1024}, F %% 256 == 0, mode 0..2");
+    KEEP_ON_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    Tmp t;
+    const bool lo = mode == 1, q = mode == 2;
+    f16 *w1h = t.get<f16>(F * D), *w1l = t.get<f16>(F * D), *w2h = t.get<f16>(D * F), *w2l = t.get<f16>(D * F);
+    f16 *xh = t.get<f16>(blk_elems(M, D)), *xl = t.get<f16>(blk_elems(M, D)), *mh = t.get<f16>(blk_elems(M, F)), *ml = t.get<f16>(blk_elems(M, F));
+    unsigned char *w1q = t.get<unsigned char>(keepk::q4_data_bytes(F, D)), *w1s = t.get<unsigned char>(keepk::q4_scale_bytes(F, D));
+    unsigned char *w2q = t.get<unsigned char>(keepk::q4_data_bytes(D, F)), *w2s = t.get<unsigned char>(keepk::q4_scale_bytes(D, F));
+    unsigned char *xq = t.get<unsigned char>(keepk::q4_data_bytes(M, D)), *xs = t.get<unsigned char>(keepk::q4_scale_bytes(M, D));
+    unsigned char *mq = t.get<unsigned char>(keepk::q4_data_bytes(M, F)), *ms = t.get<unsigned char>(keepk::q4_scale_bytes(M, F));
+    float* ws = t.get<float>(SKINNY_WS_BYTES / 4);
+    if (!w1h || !w1l || !w2h || !w2l || !xh || !xl || !mh || !ml || !w1q || !w1s || !w2q || !w2s || !xq || !xs || !mq || !ms || !ws) return h->fail(KEEP_ENOMEM, "temp alloc");
+    launch_quant_blockify(fc1_w, w1h, w1l, w1q, w1s, (int)F, (int)D, s);
+    launch_quant_blockify(fc2_w, w2h, w2l, w2q, w2s, (int)D, (int)F, s);
+    HIPCHK(h, hipMemcpyAsync(out, x, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LnParams ln{};
+    ln.tune = &h->tune;
+    ln.x = x; ln.x_stride = D; ln.rows = (int)M; ln.D = (int)D; ln.eps = 1e-6f; ln.gamma = ln_w; ln.beta = ln_b;
+    ln.out_hi = xh; ln.out_lo = lo ? xl : nullptr; ln.out_kt = (int)(D / 32); ln.out_q = q ? xq : nullptr; ln.out_sc = q ? xs : nullptr;
+    if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: layernorm");
+    GemmParams p{};
+    p.tune = &h->tune; p.patches_per_img = 196; p.splitk_ws = ws; p.splitk_bytes = SKINNY_WS_BYTES;
+    p.a_hi = xh; p.a_lo = xl; p.w_hi = w1h; p.w_lo = w1l; p.M = (int)M; p.N = (int)F; p.K = (int)D; p.nseg = lo ? 3 : 1; p.bias = fc1_b;
+    p.out_hi = mh; p.out_lo = lo ? ml : nullptr; p.out_kt = (int)(F / 32);
+    if (q) { p.comp = 1; p.a_q = xq; p.a_sc = xs; p.w_q = w1q; p.w_sc = w1s; p.out_q = mq; p.out_sc = ms; }
+    if (launch_gemm_f16(p, EPI_GELU_F16, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: fc1");
+    GemmParams r{};
+    r.tune = &h->tune; r.patches_per_img = 196; r.splitk_ws = ws; r.splitk_bytes = SKINNY_WS_BYTES;
+    r.a_hi = mh; r.a_lo = ml; r.w_hi = w2h; r.w_lo = w2l; r.M = (int)M; r.N = (int)D; r.K = (int)F; r.nseg = lo ? 3 : 1; r.bias = fc2_b;
+    r.ls = ls; r.resid = out;
+    if (q) { r.comp = 1; r.a_q = mq; r.a_sc = ms; r.w_q = w2q; r.w_sc = w2s; }
+    if (launch_gemm_f16(r, EPI_RESID_LS, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: fc2");
+    HIPCHK(h, hipStreamSynchronize(s));
+    return check_launch(h, "op_mlp");
 }
 
 int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int64_t B, int64_t T, int heads, int split,
                       float* out, void* stream) {
     if (!h || !qkv || !out || B < 1 || T < 1 || heads < 1) return h ? h->fail(KEEP_EINVAL, "bad attention arguments") : KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = B * T, D = (int64_t)heads * 64;
     Tmp t;
@@ -1260,6 +1406,7 @@ int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int
     if (!q_hi || !q_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
     launch_split_f16(qkv, q_hi, q_lo, M * 3 * D, s);
     AttnParams a{};
+    a.tune = &h->tune;
     a.qkv_hi = q_hi; a.qkv_lo = q_lo; a.out_hi = o_hi; a.out_lo = split ? o_lo : nullptr; a.mask = mask;
     a.batch = (int)B; a.ntok = (int)T; a.heads = heads; a.split = split; a.scale = 0.125f; a.out_kt = (int)(D / 32);
     if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
@@ -1271,8 +1418,9 @@ int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int
 int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const float* gamma, const float* beta, int64_t rows,
                       int64_t D, float eps, float* out, void* stream) {
     if (!h || !x || !gamma || !beta || !out || rows < 1) return h ? h->fail(KEEP_EINVAL, "bad layernorm arguments") : KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     LnParams p{};
+    p.tune = &h->tune;
     p.x = x; p.x_stride = D; p.add = add; p.gamma = gamma; p.beta = beta; p.rows = (int)rows; p.D = (int)D; p.eps = eps;
     p.out_f32 = out; p.out_f32_stride = D;
     if (launch_layernorm(p, (hipStream_t)stream)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %lld", (long long)D);
@@ -1282,8 +1430,9 @@ int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const fl
 int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* bias, int64_t M, int64_t N, int64_t K, float scale,
                   int act, float* out, void* stream) {
     if (!h || !a || !b || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     SgemmParams g{};
+    g.tune = &h->tune;
     g.a = a; g.lda = K; g.b = b; g.ldb = K; g.out = out; g.ldo = N; g.bias = bias; g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.scale = scale; g.act = act;
     if (launch_sgemm_f32(g, (hipStream_t)stream)) return h->fail(KEEP_EUNSUPPORTED, "sgemm needs K%%16==0");
@@ -1291,15 +1440,16 @@ int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* b
 }
 
 int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes) {
-    if (!h || !host_dst || !g_gemm_dbg || bytes > (int64_t)65536 * 4 * 8) return KEEP_EINVAL;
+    if (!h || !host_dst || !h->tune.dbg || bytes > (int64_t)65536 * 4 * 8) return KEEP_EINVAL;      // diagnostics builds only
+    KEEP_ON_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
-    HIPCHK(h, hipMemcpy(host_dst, g_gemm_dbg, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(host_dst, h->tune.dbg, bytes, hipMemcpyDeviceToHost));
     return KEEP_OK;
 }
 
 int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream) {
     if (!h || !x || rows < 1 || D < 1) return h ? h->fail(KEEP_EINVAL, "bad l2norm arguments") : KEEP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    KEEP_ON_DEVICE(h);
     launch_l2norm_rows(x, (int)rows, (int)D, 1e-12f, (hipStream_t)stream);
     return check_launch(h, "op_l2norm");
 }

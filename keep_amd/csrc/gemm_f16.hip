@@ -18,6 +18,7 @@
 //     accumulators (strict precision mode)
 #include "gemm_epilogue.h"
 
+#ifdef KEEP_EXPERIMENTS
 namespace keepk {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -141,33 +142,36 @@ void gemm_f16_nt_kernel(GemmParams p) {
 
 }  // namespace keepk
 using namespace keepk;
+#endif
+
 
 int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s);
 int launch_gemm_f16_v3(const GemmParams& p, int epi, hipStream_t s);
-int g_gemm_ablate = 0;
-long long* g_gemm_dbg = nullptr;
-int g_gemm_skinny_m = 320;   // calls with M <= this many rows take the register-direct split-K kernel (0: never).  Above it the
-                             // K-sliced 256x256 kernel is faster: 2 tiles (394 rows) 2.57 -> 2.36 ms, 4 tiles (788) 3.45 -> 2.83 ms
-int g_gemm_splitk_tiles = 64;    // mid-size calls: a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never).
-                                 // Measured: 64 -> encode_image of 8 / 16 tiles 4.43 -> 3.27 / 4.78 -> 4.00 ms; at 160 the fp32
-                                 // partial traffic costs more than the idle CUs did (16 tiles 5.12 ms, 64 tiles 11.8 vs 9.9)
-int g_gemm_impl = 0;     // 0 auto, 1 force v1 (128x128 register-staged), 256 / 128 force that v2 variant
-
 int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
-    // Operands in blk layout -> the LDS-DMA kernels (gemm_f16_v2.hip); g_gemm_impl only picks the tile width.
+    // Operands in blk layout -> the LDS-DMA kernels (gemm_f16_v2.hip); tune->gemm_impl only picks the tile width.
+    static const KeepTune defaults;
     GemmParams p = p_in;
-    p.ablate = g_gemm_ablate;
-    p.dbg = g_gemm_dbg;
-    int impl = g_gemm_impl;
-    if (impl == 0 && p.M <= g_gemm_skinny_m && p.M <= SKINNY_MAX_M && p.splitk_ws) {
+    const KeepTune& t = p.tune ? *p.tune : defaults;
+#ifdef KEEP_DIAGNOSTICS
+    p.ablate = t.gemm_ablate;
+    p.dbg = t.dbg;
+#else
+    p.ablate = 0;
+    p.dbg = nullptr;
+#endif
+    int impl = t.gemm_impl;
+    if (p.comp) {                                    // compensated product: always the 256x256 kernel (callers route small M through nseg = 3)
+        return launch_gemm_f16_v2(p, epi, 256, s) == 0 ? 0 : -1;
+    }
+    if (impl == 0 && p.M <= t.gemm_skinny_m && p.M <= SKINNY_MAX_M && p.splitk_ws) {
         const int rc = launch_gemm_f16_skinny(p, epi, p.splitk_ws, p.splitk_bytes, s);
         if (rc >= 0) return rc;
     }
-    if (impl == 0 && g_gemm_splitk_tiles > 0 && p.splitk_ws && p.N % 256 == 0 && p.K % 32 == 0) {
+    if (impl == 0 && t.gemm_splitk_tiles > 0 && p.splitk_ws && p.N % 256 == 0 && p.K % 32 == 0) {
         // Between the small-M kernel and a full machine: ceil(M/256) * N/256 tiles on 256 CUs, each walking all of K alone.
         // Cut K into S slices (>= 8 steps each), fp32 partials, then the shared reduce + epilogue kernel.
         const int tiles = ((p.M + 255) / 256) * (p.N / 256), KT = p.K / 32;
-        int S = tiles < g_gemm_splitk_tiles ? 256 / tiles : 1;
+        int S = tiles < t.gemm_splitk_tiles ? 256 / tiles : 1;
         if (S > 8) S = 8;
         if (S > KT / 8) S = KT / 8;
         if (S >= 2 && (size_t)S * p.M * p.N * sizeof(float) <= p.splitk_bytes) {
@@ -176,12 +180,16 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
             if (launch_gemm_f16_v2(q, EPI_PARTIAL, 256, s) == 0) return launch_gemm_splitk_reduce(p, epi, p.splitk_ws, S, s);
         }
     }
+#ifdef KEEP_EXPERIMENTS
     if (impl == 3 && launch_gemm_f16_v3(p, epi, s) == 0) return 0;     // persistent 256x256 variant
-    if ((impl != 128 && impl != 256 && impl != 2128 && impl != 3256 && impl != 4256) || ((impl == 256 || impl == 3256 || impl == 4256) && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
+    if (impl == 2128 || impl == 3256 || impl == 4256) { if (launch_gemm_f16_v2(p, epi, impl, s) == 0) return 0; }
+#endif
+    if ((impl != 128 && impl != 256) || (impl == 256 && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
     launch_gemm_f16_v2(p, epi, impl, s);
     return 0;
 }
 
+#ifdef KEEP_EXPERIMENTS
 // Row-major operands: the register-staged 128x128 kernel above (cross-check variant for the op tests).
 void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s) {
     dim3 grid(p.N / BN, (p.M + BM - 1) / BM), block(THREADS);
@@ -193,3 +201,6 @@ void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s) {
         default:            hipLaunchKernelGGL(gemm_f16_nt_kernel<EPI_RESID_F32>, grid, block, 0, s, p); break;
     }
 }
+#else
+void launch_gemm_f16_rowmajor(const GemmParams&, int, hipStream_t) {}     // cross-check kernel: experiment builds only
+#endif

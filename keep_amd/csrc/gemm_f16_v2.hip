@@ -17,6 +17,7 @@
 //     DMA queue to zero), and the DMA for tile s+NSTAGE-1 is issued right after that barrier
 //   * nseg == 3: hi/lo split product through the same accumulators (strict precision)
 #include "gemm_epilogue.h"
+#include "quant4.h"
 
 // Cache-policy bits of the two LDS-DMA streams (aux operand of global_load_lds: 2 = nt).  Tuning knobs for
 // tools/ab experiments (KEEP_BUILD_DEFINES); both default to the plain policy.
@@ -51,7 +52,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // needs the whole 512-entry file of its SIMD
 constexpr int v2_waves_per_simd(int BN, int WM, int WN) { return (V2_BM / WM / 32) * (BN / WN / 32) * 16 > 128 ? 1 : 2; }
 
-template <int BN, int WM, int WN, int NSTAGE, int EPI>
+typedef int v8i __attribute__((ext_vector_type(8)));
+constexpr int V2_ST2 = 34816;        // phase-2 LDS stage: 16 KiB A planes + 16 KiB W planes + 1 KiB + 1 KiB of scales (one K = 64 chunk)
+constexpr int V2_NST2 = 4;
+
+template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP = false>
 __global__ __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BN, WM, WN))
 void gemm_f16_v2_kernel(GemmParams p) {
     constexpr int V2_THREADS = WM * WN * 64;
@@ -251,6 +256,69 @@ void gemm_f16_v2_kernel(GemmParams p) {
     mfma_group(fw1, fa1);
 #undef KEEP_PIN
 
+    // ---- phase 2: the two correction terms  W_lo A_hi^T + W_hi A_lo^T  on the MX-fp4 pipe (quant4.h) ------------------
+    // Same accumulators, same wave tiling; K advances 64 per step (one v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile
+    // and term: 32 cycles per SIMD against 4 x 32 for the fp16 pass over the same K).  Per step a workgroup streams
+    // 34 KiB (fp16 pass: 64 KiB per K = 64) through its own 4-stage LDS-DMA ring: 3 chunks in flight, counted vmcnt,
+    // one raw barrier per chunk.
+    if constexpr (COMP) {
+        static_assert(BN == 256 && WM == 2 && WN == 4, "phase 2 is written for the 2 x 4 wave grid of the 256 x 256 tile");
+        constexpr int G2 = 5;                                   // DMA instructions per wave per chunk
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the phase-1 ring (its DMA queue is already drained)
+        const int NC = p.K >> 6;
+        const unsigned char* aq = p.a_q + (int64_t)(m0 >> 8) * KT * 8192;
+        const unsigned char* wq = p.w_q + (int64_t)(n0 >> 8) * KT * 8192;
+        const unsigned char* sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512) + (wave & 3) * 256 + lane * 4;
+        auto stage2 = [&](int c, int buf) {
+            unsigned char* sb = smem_raw + buf * V2_ST2;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(aq + (int64_t)c * 16384 + (r * 512 + tid) * 16), (lptr_t)(sb + (r * 512 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(wq + (int64_t)c * 16384 + (r * 512 + tid) * 16), (lptr_t)(sb + 16384 + (r * 512 + wave * 64) * 16), 16, 0, 0);
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)(sq + (int64_t)c * 1024), (lptr_t)(sb + 32768 + (wave >> 2) * 1024 + (wave & 3) * 256), 4, 0, 0);
+        };
+#pragma unroll
+        for (int t = 0; t < V2_NST2 - 1; ++t)
+            if (t < NC) stage2(t, t);
+        if (NC >= V2_NST2 - 1) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int a_row = (wm * 128 + frow) * 16, w_row = (wn * 64 + frow) * 16;
+        const int asc_off = 32768 + fhi * 512 + (wm * 32 + frow) * 4, wsc_off = 32768 + 1024 + fhi * 512 + ((wn >> 1) * 32 + frow) * 4;
+        const int wsh = (wn & 1) * 16;
+        for (int c = 0; c < NC; ++c) {
+            const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
+            const unsigned char* sa = sb + fhi * 8192;                  // this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31
+            const unsigned char* sw = sb + 16384 + fhi * 8192;
+            uint4 ah[4], al[4], wh[2], wl[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ah[j] = *reinterpret_cast<const uint4*>(sa + a_row + j * 512);
+                al[j] = *reinterpret_cast<const uint4*>(sa + 4096 + a_row + j * 512);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wh[i] = *reinterpret_cast<const uint4*>(sw + w_row + i * 512);
+                wl[i] = *reinterpret_cast<const uint4*>(sw + 4096 + w_row + i * 512);
+            }
+            const int sah = *reinterpret_cast<const int*>(sb + asc_off), sal = *reinterpret_cast<const int*>(sb + asc_off + 256);
+            const int swh = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off) >> wsh), swl = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off + 256) >> wsh);
+            if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));
+#define KEEP_V8(V_) v8i{(int)(V_).x, (int)(V_).y, (int)(V_).z, (int)(V_).w, 0, 0, 0, 0}
+#define KEEP_MX(I, J) \
+            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah); \
+            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
+            KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)
+            KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)
+#undef KEEP_MX
+#undef KEEP_V8
+            if (c + V2_NST2 - 1 < NC) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
     if (p.dbg) t_loop = __builtin_readcyclecounter();
 
     // ---- epilogue through LDS ---------------------------------------------------------------------
@@ -318,7 +386,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     f32x2 a = {acc[i][j][rg * 4 + 0] + bfrag[i * 4 + rg][0], acc[i][j][rg * 4 + 1] + bfrag[i * 4 + rg][1]};
                     f32x2 b = {acc[i][j][rg * 4 + 2] + bfrag[i * 4 + rg][2], acc[i][j][rg * 4 + 3] + bfrag[i * 4 + rg][3]};
                     if (EPI == EPI_GELU_F16) {
-                        if (p.out_lo) { a = gelu_fast2(a); b = gelu_fast2(b); }            // strict: full-accuracy polynomial
+                        if (p.out_lo || p.out_q) { a = gelu_fast2(a); b = gelu_fast2(b); }  // strict / compensated: full-accuracy polynomial
                         else { a = gelu_fast2_fp16(a); b = gelu_fast2_fp16(b); }
                     }
                     f16x4 h, l;
@@ -329,7 +397,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     split_f16(b[1], hh, ll); h[3] = hh; l[3] = ll;
                     const int so = frow * PITCH16 + i * 32 + 8 * rg + 4 * fhi;
                     *reinterpret_cast<f16x4*>(slab_hi + so) = h;
-                    if (p.out_lo) *reinterpret_cast<f16x4*>(slab_lo + so) = l;
+                    if (p.out_lo || p.out_q) *reinterpret_cast<f16x4*>(slab_lo + so) = l;
                 }
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
@@ -339,7 +407,12 @@ void gemm_f16_v2_kernel(GemmParams p) {
                 if (m < p.M) {
                     const int64_t o = p.out_kt > 0 ? blk_off(m, ncol, p.out_kt) : (int64_t)m * p.N + ncol;
                     *reinterpret_cast<f16x8*>(p.out_hi + o) = h;
-                    if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = *reinterpret_cast<const f16x8*>(slab_lo + r * PITCH16 + ocol);
+                    if (p.out_lo || p.out_q) {
+                        const f16x8 l = *reinterpret_cast<const f16x8*>(slab_lo + r * PITCH16 + ocol);
+                        if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = l;
+                        // this GEMM's N is the consumer's K: 8 lanes cover the wave's 64 columns = two MX blocks of 4 lanes each
+                        if (p.out_q) q4_store8(p.out_q, p.out_sc, p.out_kt, m, ncol >> 5, (ocol >> 3) & 3, h, l);
+                    }
                 }
             }
         } else {
@@ -380,29 +453,39 @@ void gemm_f16_v2_kernel(GemmParams p) {
     }
 }
 
+// hipFuncSetAttribute is per device: remember per kernel instantiation which devices have been opted in
+template <class K>
+bool v2_opt_in_lds(K kernel, size_t bytes) {
+    static unsigned long long done = 0;              // bit d: device d
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev < 64 && (done >> dev) & 1ull) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    if (dev < 64) done |= 1ull << dev;
+    return true;
+}
+
+template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP>
+int launch_v2_one(const GemmParams& p, hipStream_t s) {
+    constexpr size_t ring = (size_t)NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
+    constexpr size_t lds_bytes = COMP && (size_t)V2_NST2 * V2_ST2 > ring ? (size_t)V2_NST2 * V2_ST2 : ring;
+    auto kernel = &gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI, COMP>;
+    if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
+    const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM) * (EPI == EPI_PARTIAL ? p.ksplit : 1);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WM * WN * 64), lds_bytes, s, p);
+    return 0;
+}
+
 template <int BN, int WM, int WN, int NSTAGE>
 int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
-    static bool attr_set = false;
-    if (!attr_set) {
-#define KEEP_SET_ATTR(E) if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, E>), \
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
-        KEEP_SET_ATTR(EPI_F16) KEEP_SET_ATTR(EPI_GELU_F16) KEEP_SET_ATTR(EPI_RESID_LS) KEEP_SET_ATTR(EPI_PATCH) KEEP_SET_ATTR(EPI_RESID_F32)
-        KEEP_SET_ATTR(EPI_PARTIAL)
-#undef KEEP_SET_ATTR
-        attr_set = true;
-    }
-    const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM) * (epi == EPI_PARTIAL ? p.ksplit : 1);
-    dim3 g(grid), b(WM * WN * 64);
     switch (epi) {
-        case EPI_F16:      hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_F16>), g, b, lds_bytes, s, p); break;
-        case EPI_GELU_F16: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_GELU_F16>), g, b, lds_bytes, s, p); break;
-        case EPI_RESID_LS: hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_RESID_LS>), g, b, lds_bytes, s, p); break;
-        case EPI_PATCH:    hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_PATCH>), g, b, lds_bytes, s, p); break;
-        case EPI_PARTIAL:  hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_PARTIAL>), g, b, lds_bytes, s, p); break;
-        default:           hipLaunchKernelGGL((gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI_RESID_F32>), g, b, lds_bytes, s, p); break;
+        case EPI_F16:      return launch_v2_one<BN, WM, WN, NSTAGE, EPI_F16, false>(p, s);
+        case EPI_GELU_F16: return launch_v2_one<BN, WM, WN, NSTAGE, EPI_GELU_F16, false>(p, s);
+        case EPI_RESID_LS: return launch_v2_one<BN, WM, WN, NSTAGE, EPI_RESID_LS, false>(p, s);
+        case EPI_PATCH:    return launch_v2_one<BN, WM, WN, NSTAGE, EPI_PATCH, false>(p, s);
+        case EPI_PARTIAL:  return launch_v2_one<BN, WM, WN, NSTAGE, EPI_PARTIAL, false>(p, s);
+        default:           return launch_v2_one<BN, WM, WN, NSTAGE, EPI_RESID_F32, false>(p, s);
     }
-    return 0;
 }
 
 }  // namespace keepk
@@ -410,17 +493,25 @@ int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
 // returns 0 if launched, 1 if the shape is not covered by this variant
 //   variant 256  : 256x256 tiles, 8 waves, one workgroup per CU
 //   variant 128  : 256x128 tiles, 8 waves (64x64 per wave)
-//   variant 2128 : 256x128 tiles, 4 waves (128x64 per wave), two workgroups per CU
+// p.comp: the 256x256 kernel with the MX-fp4 correction phase (GELU and residual epilogues: the MLP of the image tower)
 int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s) {
     using namespace keepk;
     if (p.K % V2_BK) return 1;
+    if (p.comp) {
+        if (p.N % 256 || p.K % 64 || p.nseg != 1 || !p.a_q || !p.a_sc || !p.w_q || !p.w_sc) return 1;
+        if (epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, true>(p, s);
+        if (epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, true>(p, s);
+        if (epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, true>(p, s);
+        return 1;
+    }
     if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
-    if (variant == 3256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 3>(p, epi, s);   // 96 KiB LDS: leaves room for an attention workgroup on the same CU
-    // 4 waves x 128x128 (one wave per SIMD, a third fewer LDS reads per FLOP): measured 11 % SLOWER end to end -- with no
-    // partner wave on the SIMD the ~100-cycle issue cost of each of the 8 LDS-DMA instructions per step is exposed
-    // (dealing them out one per MFMA made it worse: 12.4 vs 10.3 ms on fc2).  Kept selectable as the record of that.
-    if (variant == 4256 && p.N % 256 == 0) return launch_v2<256, 2, 2, 4>(p, epi, s);
     if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
+#ifdef KEEP_EXPERIMENTS
+    // measured-negative variants, kept as the record of the experiments: 96 KiB ring; 4 waves x 128x128
+    // (11 % slower end to end: the LDS-DMA issue cost is exposed with one wave per SIMD); 256x128 / 4 waves / two workgroups per CU
+    if (variant == 3256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 3>(p, epi, s);
+    if (variant == 4256 && p.N % 256 == 0) return launch_v2<256, 2, 2, 4>(p, epi, s);
     if (variant == 2128 && p.N % 128 == 0) return launch_v2<128, 2, 2, 3>(p, epi, s);
+#endif
     return 1;
 }

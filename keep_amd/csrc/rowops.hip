@@ -9,6 +9,7 @@
 //                    argmax of raw cosine, softmax(10*logits) (subtyping_utils.py:72) and
 //                    rank_cls_score (WSI_evaluation/utils.py:107-117)
 #include "common.h"
+#include "quant4.h"
 
 namespace keepk {
 
@@ -112,7 +113,7 @@ void layernorm_blk_kernel(LnParams p) {
             }
             if (p.out_f32 && row < p.rows) *reinterpret_cast<f32x4*>(p.out_f32 + (int64_t)row * p.out_f32_stride + col) = y;
             *reinterpret_cast<f16x4*>(s_hi + lr * PITCH + col) = h;
-            if (p.out_lo) *reinterpret_cast<f16x4*>(s_lo + lr * PITCH + col) = l;
+            if (p.out_lo || p.out_q) *reinterpret_cast<f16x4*>(s_lo + lr * PITCH + col) = l;
         }
     }
     __syncthreads();
@@ -123,8 +124,14 @@ void layernorm_blk_kernel(LnParams p) {
     if (row < p.rows) {
         for (int kt = wave * SL + lane / (4 * R); kt < KT; kt += R * SL) {
             const int64_t dst = blk_off(row, kt * 32 + ochunk, KT);
-            *reinterpret_cast<f16x8*>(p.out_hi + dst) = *reinterpret_cast<const f16x8*>(s_hi + orow * PITCH + kt * 32 + ochunk);
-            if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + dst) = *reinterpret_cast<const f16x8*>(s_lo + orow * PITCH + kt * 32 + ochunk);
+            const f16x8 h8 = *reinterpret_cast<const f16x8*>(s_hi + orow * PITCH + kt * 32 + ochunk);
+            *reinterpret_cast<f16x8*>(p.out_hi + dst) = h8;
+            if (p.out_lo || p.out_q) {
+                const f16x8 l8 = *reinterpret_cast<const f16x8*>(s_lo + orow * PITCH + kt * 32 + ochunk);
+                if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + dst) = l8;
+                // the four lanes lane&~3 .. lane|3 hold the four quarters of this (row, K slice): one MX block
+                if (p.out_q) q4_store8(p.out_q, p.out_sc, KT, row, kt, lane & 3, h8, l8);
+            }
         }
     }
 }
@@ -240,6 +247,26 @@ __global__ void split_blockify_kernel(const float* __restrict__ src, f16* __rest
         const int64_t o = blk_off(m, k, KT);
         *reinterpret_cast<f16x8*>(hi + o) = h;
         if (lo) *reinterpret_cast<f16x8*>(lo + o) = l;
+    }
+}
+// split_blockify + the MX-fp4 side planes (quant4.h).  Consecutive work items are consecutive 8-k groups of one row, so
+// four neighbouring lanes hold one 32-k block (K % 32 == 0 keeps groups from straddling rows or the grid stride).
+__global__ void quant_blockify_kernel(const float* __restrict__ src, f16* __restrict__ hi, f16* __restrict__ lo,
+                                      unsigned char* __restrict__ q, unsigned char* __restrict__ sc, int M, int K) {
+    const int Mp = (M + 255) / 256 * 256, KT = K / 32;
+    const int64_t total = (int64_t)Mp * (K / 8);
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(it / (K / 8)), k = (int)(it % (K / 8)) * 8;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = m < M ? src[(int64_t)m * K + k + e] : 0.f;
+            f16 hh, ll; split_f16(x, hh, ll); h[e] = hh; l[e] = ll;
+        }
+        const int64_t o = blk_off(m, k, KT);
+        *reinterpret_cast<f16x8*>(hi + o) = h;
+        if (lo) *reinterpret_cast<f16x8*>(lo + o) = l;
+        q4_store8(q, sc, KT, m, k >> 5, (k >> 3) & 3, h, l);
     }
 }
 __global__ void unblockify_f32_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo, float* __restrict__ out, int M, int K) {
@@ -416,11 +443,13 @@ void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, 
     hipLaunchKernelGGL(gather_rows_blk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, row_stride, dst, rows, D);
 }
 
-int g_ln_impl = 1;       // 1: LDS-transposed blk stores (layernorm_blk_kernel); 0: per-row stores
 int launch_layernorm(const LnParams& p, hipStream_t s) {
-    if (g_ln_impl == 1 && p.out_kt > 0 && p.out_hi && (p.D == 1024 || p.D == 768) && p.out_kt == p.D / 32) {
+    const int ln_impl = p.tune ? p.tune->ln_impl : 1;
+    const bool blk_ok = p.out_kt > 0 && p.out_hi && (p.D == 1024 || p.D == 768) && p.out_kt == p.D / 32;
+    if (p.out_q && !blk_ok) return -1;                  // the fp4 planes are only produced by the blk-layout kernel
+    if ((ln_impl == 1 || p.out_q) && blk_ok) {
         constexpr int R = 8;
-        const size_t lds = (size_t)R * (p.D + 32) * 2 * (p.out_lo ? 2 : 1);
+        const size_t lds = (size_t)R * (p.D + 32) * 2 * ((p.out_lo || p.out_q) ? 2 : 1);
         dim3 g((p.rows + R - 1) / R), b(R * 64);
         if (p.D == 1024) hipLaunchKernelGGL((layernorm_blk_kernel<4, R>), g, b, lds, s, p);
         else hipLaunchKernelGGL((layernorm_blk_kernel<3, R>), g, b, lds, s, p);
@@ -462,6 +491,11 @@ void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hip
     const int64_t total = (int64_t)((M + 255) / 256 * 256) * (K / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(split_blockify_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, M, K);
+}
+void launch_quant_blockify(const float* src, f16* hi, f16* lo, unsigned char* q, unsigned char* sc, int M, int K, hipStream_t s) {
+    const int64_t total = (int64_t)((M + 255) / 256 * 256) * (K / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(quant_blockify_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, q, sc, M, K);
 }
 void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s) {
     const int64_t total = (int64_t)M * K;

@@ -130,8 +130,8 @@ void sgemv_f32_nt_kernel(SgemmParams p) {
 
 }  // namespace keepk
 
-int g_sgemv_m = keepk::GEMV_MAX_M;      // rows up to which the few-row kernel is used (0: never)
 int launch_sgemm_f32(const SgemmParams& p, hipStream_t s) {
+    const int g_sgemv_m = p.tune ? p.tune->sgemv_m : keepk::GEMV_MAX_M;      // rows up to which the few-row kernel is used (0: never)
     if (p.K % keepk::SK != 0 || p.M < 1 || p.N < 1) return -1;
     if ((p.lda % 4) || (p.ldb % 4)) return -1;
     if (p.M <= g_sgemv_m && p.K <= keepk::GEMV_MAX_K && p.K % 4 == 0) {

@@ -24,7 +24,8 @@ from . import _lib
 from .config import KEEPShape
 
 _PIX = {torch.float32: _lib.PIX_F32, torch.float16: _lib.PIX_F16, torch.bfloat16: _lib.PIX_BF16}
-_PRECISIONS = {"fp16": _lib.PREC_FP16, "strict": _lib.PREC_STRICT}
+_PRECISIONS = {"fp16": _lib.PREC_FP16, "strict": _lib.PREC_STRICT, "comp": _lib.PREC_COMP}
+DEFAULT_PRECISION = "comp"     # the mode that meets the reference tolerance (cosines within 1e-4) at the lowest cost
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -38,7 +39,7 @@ def _stream(device: torch.device):
 class KEEPModel:
     """Drop-in for the reference ``KEEPModel`` (inference only)."""
 
-    def __init__(self, config: Optional[Union[KEEPShape, Mapping, str]] = None, precision: str = "fp16"):
+    def __init__(self, config: Optional[Union[KEEPShape, Mapping, str]] = None, precision: str = DEFAULT_PRECISION):
         if config is None:
             config = KEEPShape()
         elif not isinstance(config, KEEPShape):
@@ -168,7 +169,7 @@ class KEEPModel:
         self._loaded = True
 
     @classmethod
-    def from_pretrained(cls, path: str, precision: str = "fp16", **_ignored) -> "KEEPModel":
+    def from_pretrained(cls, path: str, precision: str = DEFAULT_PRECISION, **_ignored) -> "KEEPModel":
         """Load a release directory (``config.json`` + ``pytorch_model.bin`` or ``model.safetensors``),
         the local-files equivalent of ``AutoModel.from_pretrained`` at zeroshot_subtyping_WSI.py:44."""
         cfg_path = os.path.join(path, "config.json")
@@ -187,10 +188,12 @@ class KEEPModel:
         return model
 
     # ------------------------------------------------------------------ options
-    def set_precision(self, precision: str = "fp16", strict_blocks: int = 0):
-        """'fp16': fp16 MFMA operands / fp32 accumulate (fast).  'strict': hi/lo split operands,
-        three MFMA passes (fp32-class accuracy, ~3x the GEMM time).  ``strict_blocks=n`` runs only the
-        first n transformer blocks of each tower in split mode."""
+    def set_precision(self, precision: str = DEFAULT_PRECISION, strict_blocks: int = 0):
+        """'comp' (default): fp16 MFMA pass plus the first-order correction terms where the error budget needs them
+        (MX-fp4 correction passes in the image tower's MLP GEMMs, split products in its first blocks and in the text
+        tower): cosines within 1e-4 of the fp32 reference.  'fp16': single fp16 pass everywhere (fastest; ~1.5e-4, outside
+        the tolerance -- opt-in).  'strict': hi/lo split operands, three MFMA passes (4e-7, ~0.4x the speed).
+        ``strict_blocks=n`` additionally runs the first n transformer blocks of each tower in split mode."""
         self._options["precision"] = _PRECISIONS[precision]
         self._options["strict_blocks"] = int(strict_blocks)
         if self._handle.value:

@@ -60,6 +60,17 @@ class Ops:
         _lib.check(self._h, rc, "op_linear")
         return out
 
+    def mlp(self, x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, ls, mode=0):
+        """x + ls * fc2(gelu(fc1(layernorm(x)))) through the tower's kernels; mode 0 fp16, 1 split, 2 compensated."""
+        x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, ls = map(self._f, (x, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, ls))
+        M, D = x.shape
+        F = fc1_w.shape[0]
+        out = torch.empty_like(x)
+        rc = _lib.load().keep_op_mlp(self._h, _ptr(x), _ptr(ln_w), _ptr(ln_b), _ptr(fc1_w), _ptr(fc1_b), _ptr(fc2_w), _ptr(fc2_b),
+                                     _ptr(ls), M, D, F, int(mode), _ptr(out), _stream(self.device))
+        _lib.check(self._h, rc, "op_mlp")
+        return out
+
     def attention(self, qkv, B, T, heads, mask=None, split=False):
         qkv = self._f(qkv)
         m = None if mask is None else mask.to(self.device, torch.int64).contiguous()

@@ -27,10 +27,11 @@ GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 40
                (2048, 1024, 1024), (1000, 256, 192)]
 
 
-@pytest.fixture(params=[1, 128, 256, 2128, 4256, 3, 0], ids=["v1_128x128", "v2_256x128", "v2_256x256", "v2_256x128_2wg", "v2_256x256_4w", "v3_persistent", "auto_splitk"])
+@pytest.fixture(params=[128, 256, 0], ids=["v2_256x128", "v2_256x256", "auto_splitk"])
 def gemm_impl(ops, request):
-    """Run the GEMM tests once per kernel variant (variants fall back to v1 for shapes they do not tile).  0 = the
-    product's automatic choice, with the small-M split-K kernel taking every shape up to its 1024-row limit."""
+    """Run the GEMM tests once per kernel variant of the product build (256-wide falls back to 128-wide for N % 256 != 0; the
+    measured-negative variants only exist in -DKEEP_EXPERIMENTS builds).  0 = the product's automatic choice, with the
+    small-M split-K kernel taking every shape up to its 1024-row limit."""
     ops.set_option("gemm_impl", request.param)
     skinny = 320
     if request.param == 0:
@@ -88,6 +89,79 @@ def test_linear_residual_sum(ops, gemm_impl, split):
     A, W = (a.double(), w.double()) if split else (r16(a), r16(w))
     ref = resid.double() + A @ W.t() + b.double()
     assert (out - ref).abs().max() < 5e-5
+
+
+# ------------------------------------------------------------------ compensated product (fp16 pass + MX-fp4 correction terms)
+def _rel_rms(out, ref):
+    return ((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1000, 1024, 1024, EPI_F16), (394, 4096, 1024, EPI_GELU_F16), (2048, 1024, 4096, EPI_RESID_LS),
+                                       (257, 256, 64, EPI_F16), (300, 768, 3072, EPI_RESID_LS)])
+def test_compensated_linear_recovers_the_fp16_rounding(ops, M, N, K, epi):
+    """split=2: A_hi W_hi on the fp16 pipe + Q4(A_hi) Q4(W_lo) + Q4(A_lo) Q4(W_hi) on the MX-fp4 pipe.  The correction terms
+    only need 2-3 bits: the result must sit >= 4x closer to the fp64 product than the plain fp16-operand product does
+    (tools/precision_study.py: ~96 % of the rounding variance removed), on every tile position incl. the ragged M edge."""
+    a, w, b = rand(M, K, seed=21), rand(N, K, seed=22, std=0.04), rand(N, seed=23, std=0.1)
+    ls = torch.rand(N, generator=torch.Generator().manual_seed(24)) * 0.45 + 0.05
+    resid = rand(M, N, seed=25)
+    kw = dict(ls=ls, resid=resid) if epi == EPI_RESID_LS else {}
+    acc = a.double() @ w.double().t() + b.double()
+    acc16 = r16(a) @ r16(w).t() + b.double()
+    if epi == EPI_GELU_F16:
+        ref, ref16 = gelu64(acc), gelu64(acc16)
+    elif epi == EPI_RESID_LS:
+        ref, ref16 = resid.double() + ls.double() * acc, resid.double() + ls.double() * acc16
+    else:
+        ref, ref16 = acc, acc16
+    out = ops.linear(a, w, b, epi, 2, **kw).cpu().double()
+    e_comp, e_fp16 = (out - ref).abs(), (ref16 - ref).abs()
+    print(f"[comp linear {M}x{N}x{K} epi{epi}] rms err comp {e_comp.pow(2).mean().sqrt():.3e} vs fp16 operands {e_fp16.pow(2).mean().sqrt():.3e}; "
+          f"max {e_comp.max():.3e} vs {e_fp16.max():.3e}")
+    assert e_comp.pow(2).mean().sqrt() < 0.25 * e_fp16.pow(2).mean().sqrt()
+    # no tile / row / column is left uncorrected or corrupted: blockwise rms over 32 x 32 patches
+    Mb, Nb = M // 32 * 32, N // 32 * 32
+    blk = lambda e: e[:Mb, :Nb].reshape(Mb // 32, 32, Nb // 32, 32).pow(2).mean(dim=(1, 3)).sqrt()
+    assert (blk(e_comp) < 0.5 * blk(e_fp16).clamp_min(1e-12)).all()
+    assert (e_comp[Mb:] .max() if Mb < M else torch.tensor(0.)) < 4 * e_fp16.max()
+
+
+def test_compensated_linear_is_not_transposed(ops):
+    """Asymmetric operands whose fp16 rounding error is large and structured: a swapped / permuted correction operand
+    (rows, k blocks, scale bytes) would add error instead of removing it."""
+    M, N, K = 512, 512, 256
+    g = torch.Generator().manual_seed(31)
+    a = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 977) / 977.0 + 1.0 + torch.rand(M, K, generator=g) * 1e-3
+    w = ((torch.arange(N * K, dtype=torch.float32).reshape(N, K) * 7) % 1013) / 1013.0 - 0.3 + torch.rand(N, K, generator=g) * 1e-3
+    ref = a.double() @ w.double().t()
+    out = ops.linear(a, w, torch.zeros(N), EPI_RESID_LS, 2, ls=torch.ones(N), resid=torch.zeros(M, N)).cpu().double()
+    e16 = (r16(a) @ r16(w).t() - ref).abs().max().item()
+    e = (out - ref).abs().max().item()
+    print(f"[comp transposition probe] max err {e:.3e} vs fp16 operands {e16:.3e}")
+    assert e < 0.3 * e16
+
+
+@pytest.mark.parametrize("D,F,M", [(1024, 4096, 1576), (768, 3072, 520)])
+def test_mlp_block_modes(ops, D, F, M):
+    """LayerNorm -> fc1 + GELU -> fc2 + LayerScale + residual through the tower's kernels.  Mode 2 consumes the MX-fp4 side
+    planes written by the LayerNorm kernel and by the GELU epilogue (the producers of the compensated path): if either wrote
+    a wrong layout the corrections would add noise, so the error must drop well below the plain fp16 mode's and approach the
+    split mode's."""
+    x = rand(M, D, seed=41)
+    ln_w, ln_b = 1.0 + rand(D, seed=42, std=0.1), rand(D, seed=43, std=0.05)
+    w1, b1 = rand(F, D, seed=44, std=0.025), rand(F, seed=45, std=0.02)
+    w2, b2 = rand(D, F, seed=46, std=0.02), rand(D, seed=47, std=0.02)
+    ls = torch.rand(D, generator=torch.Generator().manual_seed(48)) * 0.45 + 0.05
+    xd = x.double()
+    h = torch.nn.functional.layer_norm(xd, (D,), ln_w.double(), ln_b.double(), 1e-6)
+    ref = xd + ls.double() * (gelu64(h @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
+    err = {}
+    for mode in (0, 1, 2):
+        out = ops.mlp(x, ln_w, ln_b, w1, b1, w2, b2, ls, mode).cpu().double()
+        err[mode] = (out - ref).pow(2).mean().sqrt().item()
+    print(f"[mlp D{D} M{M}] rms err: fp16 {err[0]:.3e}  split {err[1]:.3e}  compensated {err[2]:.3e}")
+    assert err[1] < 0.05 * err[0]
+    assert err[2] < 0.25 * err[0]
 
 
 def test_linear_is_not_transposed(ops, gemm_impl):

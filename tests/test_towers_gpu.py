@@ -3,15 +3,12 @@ vectors (HF BertModel / Dinov2-as-ViT-L outputs committed under tests/golden/).
 
 Tolerances (BASELINE.json north_star): cosine similarities within 1e-4 of the fp32 reference,
 argmax labels identical.
-  * 'strict' precision (hi/lo split operands, 3 MFMA passes) is held to 1e-4 everywhere and in fact
-    lands near 1e-6.
-  * the single-pass fp16 mode (the throughput mode bench.py reports) rounds every GEMM operand to
-    11 bits.  That alone gives sigma(dcos) ~ 3.5e-5 on these synthetic weights, i.e. a worst case of
-    0.9-1.5e-4 over a few hundred (tile, prompt) pairs -- predicted on the CPU by
-    oracle.encode_image(operand_dtype=float16) (8.6e-5 for the depth-2 case below, where the GPU
-    measures 1.0e-4) and irreducible without more mantissa bits per MFMA pass.  The fp16 mode is
-    therefore held to FP16_TOL = 2.5e-4 with argmax labels required to be identical, and the
-    measured value is printed; DESIGN.md "Precision" has the budget and the trade-off.
+  * 'comp' -- the DEFAULT precision and the one bench.py reports -- is held to COS_TOL = 1e-4 everywhere: fp16 MFMA pass
+    plus first-order correction terms where the error budget needs them (DESIGN.md "Precision").
+  * 'strict' (hi/lo split operands, 3 MFMA passes) is held to a few 1e-6.
+  * 'fp16' is the opt-in single-pass mode: every GEMM operand rounded to 11 bits gives sigma(dcos) ~ 3.3e-5 on these
+    synthetic weights, i.e. a worst case of 1.0-1.5e-4 -- OUTSIDE the tolerance, which is why it is not the default.  It is
+    only checked against its own documented budget FP16_TOL = 2.5e-4 (regression guard), never presented as compliant.
 """
 import os
 
@@ -27,10 +24,20 @@ from oracle import keep_oracle as O
 pytestmark = pytest.mark.gpu
 COS_TOL = 1e-4
 FP16_TOL = 2.5e-4
+MODES = ["strict", "comp", "fp16"]
+
+
+def tol(precision, strict_tol=2e-6):
+    return {"strict": strict_tol, "comp": COS_TOL, "fp16": FP16_TOL}[precision]
+
+
+_EXTRA_OPTS = {}        # engine options every model of a test gets (options belong to a handle, not to the process)
 
 
 def make_model(sd, precision):
     m = KEEPModel(precision=precision)
+    for k, v in _EXTRA_OPTS.items():
+        m.set_option(k, v)
     m.load_state_dict(sd, strict=True)
     return m.to("cuda:0").eval()
 
@@ -48,7 +55,7 @@ def text_bank():
     return torch.nn.functional.normalize(torch.randn(64, 768, generator=g), dim=-1)
 
 
-@pytest.mark.parametrize("precision", ["strict", "fp16"])
+@pytest.mark.parametrize("precision", MODES)
 def test_encode_image_depth2_vs_oracle(small, text_bank, precision):
     x = synth_tiles(5, seed=3)
     with torch.no_grad():
@@ -59,7 +66,7 @@ def test_encode_image_depth2_vs_oracle(small, text_bank, precision):
     assert torch.allclose(out.norm(dim=-1), torch.ones(5), atol=1e-5)
     dcos = (out @ text_bank.t() - ref @ text_bank.t()).abs().max().item()
     print(f"[vit d2 {precision}] max|dfeat|={(out - ref).abs().max():.3e} max|dcos|={dcos:.3e}")
-    assert dcos < (2e-6 if precision == "strict" else FP16_TOL)
+    assert dcos < tol(precision)
     assert torch.equal((out @ text_bank.t()).argmax(1), (ref @ text_bank.t()).argmax(1))
     # bf16 / fp16 pixel inputs (BASELINE config 2 feeds bf16 tiles)
     for dt in (torch.bfloat16, torch.float16):
@@ -67,10 +74,10 @@ def test_encode_image_depth2_vs_oracle(small, text_bank, precision):
         with torch.no_grad():
             ref_d = O.encode_image(small, xd.float())
         out_d = m.encode_image(xd.cuda()).cpu()
-        assert (out_d @ text_bank.t() - ref_d @ text_bank.t()).abs().max() < (2e-6 if precision == "strict" else FP16_TOL)
+        assert (out_d @ text_bank.t() - ref_d @ text_bank.t()).abs().max() < tol(precision)
 
 
-@pytest.mark.parametrize("precision", ["strict", "fp16"])
+@pytest.mark.parametrize("precision", MODES)
 def test_encode_text_2layers_vs_oracle(small, text_bank, precision):
     toks = synth_prompts(6, 256, seed=4)
     toks["attention_mask"][0, :] = 1
@@ -81,7 +88,7 @@ def test_encode_text_2layers_vs_oracle(small, text_bank, precision):
     assert out.shape == (6, 768) and out.device.type == "cpu"
     dcos = (out @ text_bank.t() - ref @ text_bank.t()).abs().max().item()
     print(f"[bert l2 {precision}] max|dfeat|={(out - ref).abs().max():.3e} max|dcos|={dcos:.3e}")
-    assert dcos < (2e-6 if precision == "strict" else FP16_TOL)
+    assert dcos < tol(precision)
     # HF defaults: no token_type_ids / attention_mask given
     out2 = m.encode_text({"input_ids": toks["input_ids"][:2]})
     with torch.no_grad():
@@ -93,7 +100,7 @@ def test_encode_text_2layers_vs_oracle(small, text_bank, precision):
         with torch.no_grad():
             r = O.encode_text(small, t)
         o = m.encode_text(t)
-        assert (o @ text_bank.t() - r @ text_bank.t()).abs().max() < (2e-6 if precision == "strict" else FP16_TOL)
+        assert (o @ text_bank.t() - r @ text_bank.t()).abs().max() < tol(precision)
 
 
 def test_padding_trim_is_invisible(small, text_bank):
@@ -184,45 +191,39 @@ def test_strict_state_dict_semantics(small):
 def no_splitk():
     """The small-M split-K GEMM (gemm_f16_skinny.hip) sums K in a different order than the 256x256 kernel, so results
     of calls that cross its row threshold agree to rounding, not bit for bit.  The bit-exactness properties below are
-    about batching / lanes / the CLS tail, so they pin the GEMM path (process-wide option) to one kernel."""
-    from keep_amd.ops import Ops
-    o = Ops()
-    o.set_option("gemm_skinny_m", 0)
-    o.set_option("gemm_splitk_tiles", 0)   # likewise the K-sliced 256x256 path of mid-size calls
-    o.set_option("sgemv_m", 0)             # and the few-row fp32 kernel of the head / pooler
+    about batching / lanes / the CLS tail, so every model they build pins its GEMM path to one kernel."""
+    _EXTRA_OPTS.update({"gemm_skinny_m": 0,        # no register-direct split-K kernel
+                        "gemm_splitk_tiles": 0,    # no K-sliced 256x256 path for mid-size calls
+                        "sgemv_m": 0})             # no few-row fp32 kernel for the head / pooler
     yield
-    o.set_option("gemm_skinny_m", 320)
-    o.set_option("gemm_splitk_tiles", 64)
-    o.set_option("sgemv_m", 16)
+    _EXTRA_OPTS.clear()
 
 
 def test_splitk_path_matches_big_kernel(small, text_bank):
     """Same inputs through both GEMM paths: equal to rounding, each path bit-reproducible."""
-    from keep_amd.ops import Ops
-    o = Ops()
     x = synth_tiles(1, seed=71).cuda()                       # M = 197 rows: register-direct split-K kernel by default
     x6 = synth_tiles(6, seed=73).cuda()
     toks = {k: v.cuda() for k, v in synth_prompts(2, 64, seed=72).items()}
-    for precision, tol in (("strict", 2e-6), ("fp16", 2e-4)):
+    for precision, ptol in (("strict", 2e-6), ("comp", 2e-4), ("fp16", 2e-4)):
         m = make_model(small, precision)
         a_img, a_txt = m.encode_image(x), m.encode_text(toks)
         assert torch.equal(m.encode_image(x), a_img) and torch.equal(m.encode_text(toks), a_txt)
         a_mid = m.encode_image(x6)                           # M = 1182 rows: 256x256 tiles cut into K slices
-        o.set_option("gemm_skinny_m", 0); o.set_option("sgemv_m", 0); o.set_option("gemm_splitk_tiles", 0)
+        m.set_option("gemm_skinny_m", 0); m.set_option("sgemv_m", 0); m.set_option("gemm_splitk_tiles", 0)
         try:
             b_img, b_txt = m.encode_image(x), m.encode_text(toks)
             b_mid = m.encode_image(x6)
         finally:
-            o.set_option("gemm_skinny_m", 320); o.set_option("sgemv_m", 16); o.set_option("gemm_splitk_tiles", 64)
+            m.set_option("gemm_skinny_m", 320); m.set_option("sgemv_m", 16); m.set_option("gemm_splitk_tiles", 64)
         d_mid = (a_mid - b_mid).abs().max().item()
         print(f"[mid-size split-K vs 256x256 {precision}] max|dfeat|={d_mid:.3e}")
-        assert d_mid < tol and torch.equal(m.encode_image(x6), a_mid)
+        assert d_mid < ptol and torch.equal(m.encode_image(x6), a_mid)
         d = max((a_img - b_img).abs().max().item(), (a_txt - b_txt).abs().max().item())
         print(f"[splitk vs 256x256 {precision}] max|dfeat|={d:.3e}")
-        assert d < tol
+        assert d < ptol
         with torch.no_grad():
             ref = O.encode_image(small, x.cpu())
-        assert ((a_img.cpu() - ref) @ text_bank.t()).abs().max() < (2e-6 if precision == "strict" else FP16_TOL)
+        assert ((a_img.cpu() - ref) @ text_bank.t()).abs().max() < tol(precision)
 
 
 def test_graph_replay_is_bit_identical(small):
@@ -269,28 +270,26 @@ def test_every_path_boundary_agrees_with_the_plain_path(small):
     """Batch sizes on both sides of every dispatch threshold (register-direct split-K <= 320 rows, graph replay <= 1024 rows,
     K-sliced 256x256 below 64 tiles, second lane from 16 tiles per lane, 256-tile sub-batches): the default engine must
     agree with the plain one (256x256 kernel only, one stream, no graphs) to rounding."""
-    from keep_amd.ops import Ops
-    o = Ops()
     sizes = (1, 2, 5, 6, 8, 13, 16, 17, 31, 32, 33, 64, 65, 100, 257)
     x = synth_tiles(max(sizes), seed=77).cuda().to(torch.bfloat16)
     toks = {k: v.cuda() for k, v in synth_prompts(70, 64, seed=78).items()}
-    for precision, tol in (("strict", 3e-6), ("fp16", 3e-4)):
+    for precision, ptol in (("strict", 3e-6), ("comp", 3e-4), ("fp16", 3e-4)):
         m = make_model(small, precision)
         got = {b: m.encode_image(x[:b]) for b in sizes}
         got_t = {pn: m.encode_text({k: v[:pn] for k, v in toks.items()}) for pn in (1, 5, 16, 17, 64, 70)}
         for k, v in (("gemm_skinny_m", 0), ("gemm_splitk_tiles", 0), ("sgemv_m", 0)):
-            o.set_option(k, v)
+            m.set_option(k, v)
         m.set_option("graphs", 0); m.set_option("streams", 1)
         try:
             plain = m.encode_image(x)
             plain_t = m.encode_text(toks)
         finally:
             for k, v in (("gemm_skinny_m", 320), ("gemm_splitk_tiles", 64), ("sgemv_m", 16)):
-                o.set_option(k, v)
+                m.set_option(k, v)
         worst = max((got[b] - plain[:b]).abs().max().item() for b in sizes)
         worst_t = max((got_t[pn] - plain_t[:pn]).abs().max().item() for pn in got_t)
         print(f"[path boundaries {precision}] image max|dfeat|={worst:.3e} text {worst_t:.3e}")
-        assert worst < tol and worst_t < tol
+        assert worst < ptol and worst_t < ptol
 
 
 def test_batch_chunking_is_invisible(small, no_splitk):
@@ -355,7 +354,7 @@ def test_cls_only_tail_is_exact(small, no_splitk):
 
 
 # ------------------------------------------------------------------ full depth vs golden (HF outputs)
-@pytest.mark.parametrize("precision", ["strict", "fp16"])
+@pytest.mark.parametrize("precision", MODES)
 def test_full_depth_image_tower_vs_golden(golden_dir, text_bank, precision):
     g = np.load(os.path.join(golden_dir, "vit_d24.npz"))
     sd = synth_state_dict(KEEPShape(), seed=int(g["weight_seed"]), text=False)
@@ -365,11 +364,11 @@ def test_full_depth_image_tower_vs_golden(golden_dir, text_bank, precision):
     ref = torch.from_numpy(g["features"])
     dcos = (out @ text_bank.t() - ref @ text_bank.t()).abs().max().item()
     print(f"[vit d24 {precision}] max|dfeat|={(out - ref).abs().max():.3e} |df|={(out - ref).norm(dim=-1).max():.3e} max|dcos|={dcos:.3e}")
-    assert dcos < (5e-6 if precision == "strict" else FP16_TOL)
+    assert dcos < tol(precision, 5e-6)
     assert torch.equal((out @ text_bank.t()).argmax(1), (ref @ text_bank.t()).argmax(1))
 
 
-@pytest.mark.parametrize("precision", ["strict", "fp16"])
+@pytest.mark.parametrize("precision", MODES)
 def test_full_depth_text_tower_vs_golden(golden_dir, text_bank, precision):
     g = np.load(os.path.join(golden_dir, "bert_l12.npz"))
     sd = synth_state_dict(KEEPShape(), seed=int(g["weight_seed"]), vision=False)
@@ -379,7 +378,7 @@ def test_full_depth_text_tower_vs_golden(golden_dir, text_bank, precision):
     ref = torch.from_numpy(g["features"])
     dcos = (out @ text_bank.t() - ref @ text_bank.t()).abs().max().item()
     print(f"[bert l12 {precision}] max|dfeat|={(out - ref).abs().max():.3e} max|dcos|={dcos:.3e}")
-    assert dcos < (5e-6 if precision == "strict" else FP16_TOL)
+    assert dcos < tol(precision, 5e-6)
 
 
 def test_bench_sized_batch_is_position_independent(no_splitk):
@@ -399,6 +398,26 @@ def test_bench_sized_batch_is_position_independent(no_splitk):
     assert (small[:2].cpu() - ref).norm(dim=-1).max() < 3e-3
 
 
+def test_compensated_mode_takes_the_fp4_path_on_bench_sized_lanes(small, text_bank):
+    """Lanes of >= 32 tiles run fc1 / fc2 as fp16 pass + MX-fp4 correction terms (smaller calls use split products, which
+    the other tests cover): 64 tiles = two lanes of 32.  Held to the tolerance, and required to beat the plain fp16 mode."""
+    x = synth_tiles(64, seed=91)
+    with torch.no_grad():
+        ref = O.encode_image(small, x) @ text_bank.t()
+    errs = {}
+    for name, precision, opts in (("fp16", "fp16", {}), ("comp", "comp", {}), ("comp, attention side plain", "comp", {"comp_full_blocks": 0}),
+                                  ("comp, one lane", "comp", {"streams": 1})):
+        m = make_model(small, precision)
+        for k, v in opts.items():
+            m.set_option(k, v)
+        d = (m.encode_image(x.cuda()).cpu() @ text_bank.t() - ref).abs()
+        errs[name] = (d.max().item(), d.pow(2).mean().sqrt().item())
+        print(f"[64 tiles d2 {name}] max|dcos|={errs[name][0]:.3e} rms={errs[name][1]:.3e}")
+    assert errs["comp"][0] < COS_TOL and errs["comp, one lane"][0] < COS_TOL
+    assert errs["comp"][1] < 0.5 * errs["fp16"][1]
+    assert errs["comp, attention side plain"][1] < 0.8 * errs["fp16"][1]
+
+
 def test_dual_tower_similarity_full_depth():
     """Config 3 in miniature: 16 tiles x 8 prompts through both towers, sim matrix + argmax."""
     sd = synth_state_dict(KEEPShape(), seed=31)
@@ -406,12 +425,13 @@ def test_dual_tower_similarity_full_depth():
     with torch.no_grad():
         ri, rt = O.encode_image(sd, x), O.encode_text(sd, toks)
     ref = O.similarity(ri, rt)
-    for precision, tol in (("strict", 5e-6), ("fp16", FP16_TOL)):
+    for precision in MODES:
+        ptol = tol(precision, 5e-6)
         m = make_model(sd, precision)
         sim, lab = m.similarity(m.encode_image(x.cuda()), m.encode_text({k: v.cuda() for k, v in toks.items()}), mode="argmax")
         d = (sim.cpu() - ref).abs().max().item()
         print(f"[dual {precision}] max|dcos|={d:.3e}")
-        assert d < tol
+        assert d < ptol
         assert torch.equal(lab.cpu(), O.sim_argmax(ref))
 
 

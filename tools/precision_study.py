@@ -19,11 +19,13 @@ from oracle import keep_oracle as O
 
 torch.set_num_threads(os.cpu_count())
 NT = int(os.environ.get("TILES", "8"))
-sd = synth_state_dict(KEEPShape(), seed=0, text=False)
-x = synth_tiles(NT, seed=100)
-bank = torch.nn.functional.normalize(torch.randn(64, 768, generator=torch.Generator().manual_seed(3)), dim=-1)
+DEV = "cuda" if torch.cuda.is_available() else "cpu"       # pure torch fp32 arithmetic either way (the GPU only makes it fast)
+torch.backends.cuda.matmul.allow_tf32 = False
+sd = {k: v.to(DEV) for k, v in synth_state_dict(KEEPShape(), seed=0, text=False).items()}
+x = synth_tiles(NT, seed=100).to(DEV)
+bank = torch.nn.functional.normalize(torch.randn(64, 768, generator=torch.Generator().manual_seed(3)), dim=-1).to(DEV)
 r16 = lambda t: t.to(torch.float16).to(torch.float32)
-E2M1 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+E2M1 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], device="cuda" if torch.cuda.is_available() else "cpu")
 
 
 def q_fp8(t, prescale=1.0):
@@ -117,7 +119,7 @@ def main():
             tot = sum(vs.values())
             print({s: round(v / tot, 3) for s, v in vs.items()})
         elif what == "scheme":
-            for name in sys.argv[2:]:
+            for name in (sys.argv[2:] or sorted(SCHEMES)):
                 report(name, SCHEMES[name], ref)
 
 
