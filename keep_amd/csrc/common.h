@@ -83,6 +83,10 @@ enum GemmEpi : int {
     EPI_RESID_F32= 4,   // out_f32 = acc + bias + resid      (BERT pre-LN sum; may alias resid)
     EPI_PARTIAL  = 5,   // internal: fp32 partial sums of one K slice -> splitk_ws[slice][M][N] (no bias); the
                         // split-K reduce kernel of gemm_f16_skinny.hip then applies the real epilogue
+    EPI_TOP2     = 6,   // prompt screening (WSI_evaluation/utils.py:107-130): columns are K classifiers x C classes (C = 2 or 4,
+                        // consecutive); per (row, classifier) top-2 margin score (v1 - v2) - |v1 + v2 - 1| taken in the
+                        // accumulator registers and summed over the tile's rows -> top2_partial[row slot][classifier].
+                        // No logit is ever written.
 };
 
 struct GemmParams {
@@ -108,6 +112,7 @@ struct GemmParams {
     // launch_gemm_f16 reports through its return value whether it was applied (bit 0) -- the big kernel never does
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     f16* ln_out_hi; f16* ln_out_lo; float* ln_out_f32;   // fp16 in blk layout (KT = N / 32); fp32 row-major [M][N], may alias resid / out_f32
+    int top2_c; float* top2_partial; int top2_kpad;   // EPI_TOP2: classes per classifier, [2 * ceil(M/256)][top2_kpad] partial sums
     int ksplit;                           // internal (EPI_PARTIAL): number of K slices the grid is replicated over
     float* splitk_ws; size_t splitk_bytes; // scratch for the small-M split-K kernel (gemm_f16_skinny.hip); null: never used
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
@@ -192,6 +197,7 @@ void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, 
 
 // wsi.hip
 void launch_group_top2(const float* logits, int n, int K, int C, float* partial, int max_row_blocks, float* sums, hipStream_t s);
+void launch_top2_slots_reduce(const float* partial, int nslots, int kpad, int K, float scale, float* out, hipStream_t s);
 void launch_scale_vec(const float* in, int n, float f, float* out, hipStream_t s);
 int launch_sim_small(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax,
                      hipStream_t s);            // 0 handled, -1 not eligible (P > 8, D not 768/1024)

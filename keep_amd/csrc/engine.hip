@@ -84,6 +84,7 @@ struct keep_handle {
     int strict_blocks = 0;       // first n blocks / layers as full hi/lo split products (any mode)
     int comp_full_blocks = 2;    // KEEP_PREC_COMP: first n ViT blocks run qkv / attention / proj as split products as well
     int comp_mlp_blocks = 12;    // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
+    int fused_screening = 1;     // keep_prompt_scores: 1 fused compensated GEMM (default) | 2 fused 3-pass split GEMM | 0 logits through HBM (any C)
     int comp_min_tiles = 32;     // lanes with fewer tiles take the split product where a compensated one is asked for (small-M kernels)
     int max_tiles = 256;
     int max_prompts = 64;
@@ -895,6 +896,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
     else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
     else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
+    else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
@@ -1174,6 +1176,38 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
     hipStream_t s = (hipStream_t)stream;
     Scope sc(h, T_SIM, s);
     const int64_t KC = K * C;
+    if ((C == 2 || C == 4) && D % 64 == 0 && h->fused_screening) {
+        // Fused path: ONE compensated GEMM [N,D] x [D,K*C] whose epilogue takes the per-(tile, classifier)
+        // top-2 score in the accumulator registers and sums it over the tile's rows; no logit reaches HBM.
+        const int64_t KCp = (KC + 255) / 256 * 256, nslots = (N + 255) / 256 * 2, kpad = KCp / C;
+        const bool comp = h->fused_screening == 1;                      // 1: fp16 + MX-fp4 corrections; 2: three fp16 passes
+        Carver cv(nullptr);
+        const size_t o_ahi = cv.off; cv.take<f16>(blk_elems(N, D));
+        const size_t o_alo = cv.off; cv.take<f16>(comp ? 0 : blk_elems(N, D));
+        const size_t o_aq = cv.off;  cv.take<unsigned char>(keepk::q4_data_bytes(N, D));
+        const size_t o_asc = cv.off; cv.take<unsigned char>(keepk::q4_scale_bytes(N, D));
+        const size_t o_whi = cv.off; cv.take<f16>(blk_elems(KCp, D));
+        const size_t o_wlo = cv.off; cv.take<f16>(blk_elems(KCp, D));
+        const size_t o_wq = cv.off;  cv.take<unsigned char>(keepk::q4_data_bytes(KCp, D));
+        const size_t o_wsc = cv.off; cv.take<unsigned char>(keepk::q4_scale_bytes(KCp, D));
+        const size_t o_part = cv.off; cv.take<float>((size_t)nslots * kpad);
+        int rc = ensure_arena(h, cv.off);
+        if (rc) return rc;
+        char* a = h->arena;
+        launch_quant_blockify(feats, (f16*)(a + o_ahi), comp ? nullptr : (f16*)(a + o_alo), (unsigned char*)(a + o_aq), (unsigned char*)(a + o_asc), (int)N, (int)D, s);
+        launch_quant_blockify(bank, (f16*)(a + o_whi), (f16*)(a + o_wlo), (unsigned char*)(a + o_wq), (unsigned char*)(a + o_wsc), (int)KC, (int)D, s);
+        // (rows KC..KCp of the bank planes are zero-filled by the blockify kernel: their scores land beyond K and are never read)
+        GemmParams p{};
+        p.tune = &h->tune;
+        p.a_hi = (f16*)(a + o_ahi); p.a_lo = (f16*)(a + o_alo); p.w_hi = (f16*)(a + o_whi); p.w_lo = (f16*)(a + o_wlo);
+        p.M = (int)N; p.N = (int)KCp; p.K = (int)D; p.nseg = comp ? 1 : 3; p.patches_per_img = 196;
+        if (comp) { p.comp = 1; p.a_q = (unsigned char*)(a + o_aq); p.a_sc = (unsigned char*)(a + o_asc); p.w_q = (unsigned char*)(a + o_wq); p.w_sc = (unsigned char*)(a + o_wsc); }
+        p.top2_c = (int)C; p.top2_partial = (float*)(a + o_part); p.top2_kpad = (int)kpad;
+        h->prof_add_flops(T_SIM, 2.0 * N * (double)KC * D);
+        if (launch_gemm_f16(p, EPI_TOP2, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "fused prompt screening launch failed");
+        launch_top2_slots_reduce((float*)(a + o_part), (int)nslots, (int)kpad, (int)K, 1.0f / (float)N, scores_out, s);
+        return check_launch(h, "prompt_scores");
+    }
     int64_t chunk = ((int64_t)256 << 20) / (KC * 4);          // <= 256 MiB of logits alive at a time
     if (chunk < 256) chunk = 256;
     if (chunk > N) chunk = N;

@@ -160,6 +160,7 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     p.dbg = nullptr;
 #endif
     int impl = t.gemm_impl;
+    if (epi == EPI_TOP2) return launch_gemm_f16_v2(p, epi, 256, s) == 0 ? 0 : -1;      // fused prompt screening: 256x256 kernel only
     if (p.comp) {                                    // compensated product: always the 256x256 kernel (callers route small M through nseg = 3)
         return launch_gemm_f16_v2(p, epi, 256, s) == 0 ? 0 : -1;
     }

@@ -287,40 +287,100 @@ void gemm_f16_v2_kernel(GemmParams p) {
         const int a_row = (wm * 128 + frow) * 16, w_row = (wn * 64 + frow) * 16;
         const int asc_off = 32768 + fhi * 512 + (wm * 32 + frow) * 4, wsc_off = 32768 + 1024 + fhi * 512 + ((wn >> 1) * 32 + frow) * 4;
         const int wsh = (wn & 1) * 16;
-        for (int c = 0; c < NC; ++c) {
+        // Two MFMA groups per chunk, as in phase 1: group A = W_lo x A_hi, group B = W_hi x A_lo (8 instructions each).  The
+        // fragments of one group are fetched under the other group's MFMAs, the single barrier of a chunk sits between them.
+        uint4 ah[4], al[4], wh[2], wl[2];
+        int sah = 0, sal = 0, swh = 0, swl = 0;
+        auto read_a = [&](int c) {
             const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
             const unsigned char* sa = sb + fhi * 8192;                  // this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31
             const unsigned char* sw = sb + 16384 + fhi * 8192;
-            uint4 ah[4], al[4], wh[2], wl[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ah[j] = *reinterpret_cast<const uint4*>(sa + a_row + j * 512);
-                al[j] = *reinterpret_cast<const uint4*>(sa + 4096 + a_row + j * 512);
-            }
+            for (int jj = 0; jj < 4; ++jj) ah[jj] = *reinterpret_cast<const uint4*>(sa + a_row + jj * 512);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                wh[i] = *reinterpret_cast<const uint4*>(sw + w_row + i * 512);
-                wl[i] = *reinterpret_cast<const uint4*>(sw + 4096 + w_row + i * 512);
-            }
-            const int sah = *reinterpret_cast<const int*>(sb + asc_off), sal = *reinterpret_cast<const int*>(sb + asc_off + 256);
-            const int swh = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off) >> wsh), swl = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off + 256) >> wsh);
-            if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));
+            for (int ii = 0; ii < 2; ++ii) wl[ii] = *reinterpret_cast<const uint4*>(sw + 4096 + w_row + ii * 512);
+            sah = *reinterpret_cast<const int*>(sb + asc_off);
+            swl = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off + 256) >> wsh);
+        };
+        auto read_b = [&](int c) {
+            const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
+            const unsigned char* sa = sb + fhi * 8192;
+            const unsigned char* sw = sb + 16384 + fhi * 8192;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) al[jj] = *reinterpret_cast<const uint4*>(sa + 4096 + a_row + jj * 512);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) wh[ii] = *reinterpret_cast<const uint4*>(sw + w_row + ii * 512);
+            sal = *reinterpret_cast<const int*>(sb + asc_off + 256);
+            swh = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off) >> wsh);
+        };
 #define KEEP_V8(V_) v8i{(int)(V_).x, (int)(V_).y, (int)(V_).z, (int)(V_).w, 0, 0, 0, 0}
-#define KEEP_MX(I, J) \
-            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah); \
-            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
-            KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)
-            KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)
-#undef KEEP_MX
-#undef KEEP_V8
-            if (c + V2_NST2 - 1 < NC) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();
+#define KEEP_MXA(I, J) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah);
+#define KEEP_MXB(I, J) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
+#define KEEP_PIN2() __builtin_amdgcn_sched_barrier(0)
+        read_a(0);
+        for (int c = 0; c < NC; ++c) {
+            KEEP_MXA(0, 0) KEEP_MXA(0, 1) KEEP_MXA(0, 2) KEEP_MXA(0, 3)
+            KEEP_PIN2();
+            read_b(c);
+            KEEP_PIN2();
+            KEEP_MXA(1, 0) KEEP_MXA(1, 1) KEEP_MXA(1, 2) KEEP_MXA(1, 3)
+            KEEP_PIN2();
+            // chunk c+1 must have landed before anyone passes the barrier: chunks c+1, c+2 are outstanding here
+            if (c + 2 < NC) wait_vmcnt<G2>(); else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            KEEP_PIN2();
+            KEEP_MXB(0, 0) KEEP_MXB(0, 1) KEEP_MXB(0, 2) KEEP_MXB(0, 3)
+            KEEP_PIN2();
+            if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));    // overwrites the stage of chunk c-1
+            if (c + 1 < NC) read_a(c + 1);
+            KEEP_PIN2();
+            KEEP_MXB(1, 0) KEEP_MXB(1, 1) KEEP_MXB(1, 2) KEEP_MXB(1, 3)
         }
+#undef KEEP_PIN2
+#undef KEEP_MXA
+#undef KEEP_MXB
+#undef KEEP_V8
     }
 
     if (p.dbg) t_loop = __builtin_readcyclecounter();
 
+    if constexpr (EPI == EPI_TOP2) {
+        // ---- prompt-screening epilogue: everything stays in the accumulator registers --------------------------------
+        // A lane holds, per 32x32 tile (i, j) and register group rg, 4 consecutive columns n = .. + 8 rg + 4 fhi + e of ONE row
+        // m = .. + j * 32 + frow: exactly the C = 4 class logits of one classifier (or two C = 2 classifiers).  Score them,
+        // sum over this wave's 128 rows (4 tiles in-lane, then the 32 lanes of a half-wave), one store per classifier.
+        const int C = p.top2_c;
+        const int slot = (m0 >> 8) * 2 + wm;
+        float* dst = p.top2_partial + (int64_t)slot * p.top2_kpad;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const bool valid = m0 + wm * (TM * 32) + j * 32 + frow < p.M;
+                    const float v0 = acc[i][j][rg * 4 + 0], v1 = acc[i][j][rg * 4 + 1], v2 = acc[i][j][rg * 4 + 2], v3 = acc[i][j][rg * 4 + 3];
+                    const float a = fmaxf(v0, v1), b = fminf(v0, v1), c = fmaxf(v2, v3), d = fminf(v2, v3);
+                    if (C == 4) {
+                        const float t1 = fmaxf(a, c), t2 = fmaxf(fminf(a, c), fmaxf(b, d));
+                        sa += valid ? (t1 - t2) - fabsf(t1 + t2 - 1.0f) : 0.f;
+                    } else {
+                        sa += valid ? (a - b) - fabsf(a + b - 1.0f) : 0.f;
+                        sb += valid ? (c - d) - fabsf(c + d - 1.0f) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+                if (frow == 0) {
+                    const int n = n0 + wn * (TN * 32) + i * 32 + 8 * rg + 4 * fhi;
+                    if (C == 4) dst[n >> 2] = sa;
+                    else { dst[n >> 1] = sa; dst[(n >> 1) + 1] = sb; }
+                }
+            }
+        return;
+    }
     // ---- epilogue through LDS ---------------------------------------------------------------------
     // An MFMA C fragment gives a lane 4 consecutive n of ONE m, so storing straight from registers makes
     // every store instruction touch 32 different rows (measured 16k-33k cycles per tile, bound by the
@@ -502,8 +562,10 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
         if (epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, true>(p, s);
         if (epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, true>(p, s);
         if (epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, true>(p, s);
+        if (epi == EPI_TOP2) return launch_v2_one<256, 2, 4, 4, EPI_TOP2, true>(p, s);
         return 1;
     }
+    if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, false>(p, s);
     if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
     if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
 #ifdef KEEP_EXPERIMENTS

@@ -102,6 +102,15 @@ __global__ void refine_mean_kernel(const float* __restrict__ probs, const long l
     out[t] = sum / (float)cnt;
 }
 
+// sums the per-(row slot) partial scores of the fused screening GEMM (EPI_TOP2) in a fixed order -> deterministic
+__global__ __launch_bounds__(256)
+void top2_slots_reduce_kernel(const float* __restrict__ partial, int nslots, int kpad, int K, float scale, float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int b = 0; b < nslots; ++b) s += partial[(int64_t)b * kpad + k];
+    out[k] = s * scale;
+}
 __global__ void scale_vec_kernel(const float* __restrict__ in, int n, float f, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i] * f;
@@ -234,6 +243,9 @@ void launch_group_top2(const float* logits, int n, int K, int C, float* partial,
     dim3 grid((K + 255) / 256, nrb);
     hipLaunchKernelGGL(group_top2_partial_kernel, grid, dim3(256), 0, s, logits, n, K, C, rpb, partial);
     hipLaunchKernelGGL(group_top2_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, partial, nrb, K, sums);
+}
+void launch_top2_slots_reduce(const float* partial, int nslots, int kpad, int K, float scale, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(top2_slots_reduce_kernel, dim3((K + 255) / 256), dim3(256), 0, s, partial, nslots, kpad, K, scale, out);
 }
 void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
                    unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s) {

@@ -39,7 +39,8 @@ def _stream(device: torch.device):
 class KEEPModel:
     """Drop-in for the reference ``KEEPModel`` (inference only)."""
 
-    def __init__(self, config: Optional[Union[KEEPShape, Mapping, str]] = None, precision: str = DEFAULT_PRECISION):
+    def __init__(self, config: Optional[Union[KEEPShape, Mapping, str]] = None, precision: str = DEFAULT_PRECISION,
+                 towers=("image", "text")):
         if config is None:
             config = KEEPShape()
         elif not isinstance(config, KEEPShape):
@@ -53,6 +54,11 @@ class KEEPModel:
         self._host_sd: Optional[Dict[str, torch.Tensor]] = None
         self._loaded = False
         self._options = {"precision": _PRECISIONS[precision], "strict_blocks": 0}
+        # load_state_dict(strict=True) demands the keys of every tower named here (the reference's model has both,
+        # keep_inference.py:28-52); a single-tower engine -- e.g. an encode_image-only worker -- opts in with towers=("image",)
+        self.towers = tuple(towers)
+        if not self.towers or any(t not in ("image", "text") for t in self.towers):
+            raise ValueError(f"towers must be a non-empty subset of ('image', 'text'), got {towers!r}")
         self.check_token_ids = True
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
@@ -166,6 +172,15 @@ class KEEPModel:
         if rc == _lib.KEEP_EKEY:
             raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\t" + lib.keep_last_error(h).decode())
         _lib.check(h, rc, "finalize_weights")
+        if getattr(self, "_strict", True):
+            missing = []
+            if "image" in self.towers and lib.keep_vit_depth(h) == 0:
+                missing.append("visual.* / visual_head.* (image tower)")
+            if "text" in self.towers and lib.keep_bert_layers(h) == 0:
+                missing.append("text.* (text tower)")
+            if missing:
+                raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\tMissing key(s) in state_dict: " + ", ".join(missing)
+                                   + ' (construct with towers=("image",) / ("text",) for a single-tower engine)')
         self._loaded = True
 
     @classmethod
@@ -174,7 +189,7 @@ class KEEPModel:
         the local-files equivalent of ``AutoModel.from_pretrained`` at zeroshot_subtyping_WSI.py:44."""
         cfg_path = os.path.join(path, "config.json")
         config = KEEPShape.from_config_json(cfg_path) if os.path.exists(cfg_path) else KEEPShape()
-        model = cls(config, precision=precision)
+        model = cls(config, precision=precision, towers=_ignored.pop("towers", ("image", "text")))
         st = os.path.join(path, "model.safetensors")
         pt = os.path.join(path, "pytorch_model.bin")
         if os.path.exists(st):

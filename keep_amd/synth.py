@@ -116,3 +116,8 @@ def synth_tiles_device(a: int, b: int, device, dtype=torch.bfloat16, seed: int =
         block = torch.randn(unit, 3, 224, 224, device=device, generator=g, dtype=torch.float32)
         parts.append(block[max(a - u * unit, 0): min(b - u * unit, unit)].to(dtype))
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+
+def towers_of(state_dict) -> tuple:
+    """Which towers a state_dict carries -- for ``KEEPModel(towers=...)`` when a single tower is loaded on purpose."""
+    return tuple(t for t, pre in (("image", "visual."), ("text", "text.")) if any(k.startswith(pre) for k in state_dict))

@@ -42,8 +42,8 @@ def test_sharded_encode_through_rccl_matches_direct_call(nccl_world1):
     from keep_amd.synth import synth_state_dict, synth_tiles_device
     dev = torch.device("cuda", 0)
     shape = small_shape(2, 2)
-    m = KEEPModel(shape)
-    m.load_state_dict(synth_state_dict(shape, seed=3, text=False), strict=False)
+    m = KEEPModel(shape, towers=("image",))
+    m.load_state_dict(synth_state_dict(shape, seed=3, text=False), strict=True)
     m.to(dev).eval()
     n = 150                                                  # ragged: 4 full batches of 32 + one of 22
     load = lambda a, b: synth_tiles_device(a, b, dev, torch.bfloat16, seed=77, unit=64)

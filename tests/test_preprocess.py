@@ -53,7 +53,7 @@ def test_uint8_tiles_normalised_on_device(golden_dir):
     from keep_amd.config import small_shape
     from keep_amd.synth import synth_state_dict
     sd = synth_state_dict(small_shape(2, 1), seed=8, text=False)
-    m = KEEPModel(precision="strict")
+    m = KEEPModel(precision="strict", towers=("image",))
     m.load_state_dict(sd)
     m.to("cuda:0")
     img = Image.open(os.path.join(golden_dir, "example.tif")).convert("RGB").crop((37, 0, 261, 224))

@@ -18,7 +18,7 @@ import torch
 
 from keep_amd import KEEPModel
 from keep_amd.config import KEEPShape, small_shape
-from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles
+from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles, towers_of
 from oracle import keep_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -35,7 +35,7 @@ _EXTRA_OPTS = {}        # engine options every model of a test gets (options bel
 
 
 def make_model(sd, precision):
-    m = KEEPModel(precision=precision)
+    m = KEEPModel(precision=precision, towers=towers_of(sd))
     for k, v in _EXTRA_OPTS.items():
         m.set_option(k, v)
     m.load_state_dict(sd, strict=True)
@@ -185,6 +185,15 @@ def test_strict_state_dict_semantics(small):
     ok = dict(small)
     ok["text.embeddings.position_ids"] = torch.arange(512)[None].float()      # buffer of older checkpoints
     KEEPModel().to("cuda:0").load_state_dict(ok)
+    # strict=True means BOTH towers, as in the reference (keep_inference.py:83): a checkpoint without any text.* key is an
+    # error at load time, not a surprise at the first encode_text -- unless the engine was built for one tower on purpose
+    image_only = {k: v for k, v in small.items() if not k.startswith("text.")}
+    with pytest.raises(RuntimeError, match="text tower"):
+        KEEPModel().to("cuda:0").load_state_dict(image_only)
+    with pytest.raises(RuntimeError, match="image tower"):
+        KEEPModel().to("cuda:0").load_state_dict({k: v for k, v in small.items() if k.startswith("text.") or k == "logit_scale"})
+    KEEPModel(towers=("image",)).to("cuda:0").load_state_dict(image_only)
+    KEEPModel().to("cuda:0").load_state_dict(image_only, strict=False)
 
 
 @pytest.fixture()
@@ -433,6 +442,60 @@ def test_dual_tower_similarity_full_depth():
         print(f"[dual {precision}] max|dcos|={d:.3e}")
         assert d < ptol
         assert torch.equal(lab.cpu(), O.sim_argmax(ref))
+
+
+def test_config3_fixture_first_chunk(golden_dir):
+    """BASELINE config 3 against the committed fp32-oracle fixture (tools/make_golden.py c3; bench.py runs all 4096 tiles):
+    the first 256 tiles x 64 prompts through both towers = 16 384 cosines.  Default mode inside 1e-4; a tile's label may only
+    differ from the oracle's where the oracle's own top-2 margin is smaller than twice the cosine error."""
+    g = np.load(os.path.join(golden_dir, "c3_dual_tower.npz"))
+    sd = synth_state_dict(KEEPShape(), seed=int(g["weight_seed"]))
+    chunk = int(g["chunk"])
+    x = synth_tiles(chunk, seed=int(g["tile_seed0"]))
+    assert abs(float(x.double().abs().sum()) - float(g["tiles0_checksum"])) < 1e-3 * float(g["tiles0_checksum"])
+    toks = {"input_ids": torch.from_numpy(g["input_ids"].astype(np.int64)), "attention_mask": torch.from_numpy(g["attention_mask"].astype(np.int64))}
+    toks["token_type_ids"] = torch.zeros_like(toks["input_ids"])
+    ref = torch.from_numpy(g["sims"][:chunk])
+    ref_lab, margin = torch.from_numpy(g["argmax"][:chunk].astype(np.int64)), torch.from_numpy(g["margin"][:chunk])
+    for precision in ("comp", "strict"):
+        m = make_model(sd, precision)
+        sim, lab = m.similarity(m.encode_image(x.cuda()), m.encode_text({k: v.cuda() for k, v in toks.items()}), mode="argmax")
+        d = (sim.cpu() - ref).abs()
+        differ = lab.cpu().long() != ref_lab
+        print(f"[c3 first chunk {precision}] max|dcos|={d.max():.3e} rms={d.pow(2).mean().sqrt():.3e} labels differing {int(differ.sum())} "
+              f"(largest oracle margin among them {float(margin[differ].max()) if differ.any() else 0.0:.2e})")
+        assert d.max() < tol(precision, 5e-6)
+        assert not (differ & (margin > 2 * d.max())).any()
+
+
+def test_near_tie_argmax(text_bank):
+    """Two prompts ~1e-4 apart in cosine for a typical tile (t2 = t1 nudged by 3e-3 along a random direction): the labels
+    the engine assigns must be the oracle's wherever the oracle's margin exceeds the engine's own cosine error, in both the
+    default and the strict mode; strict must get (practically) every tile right."""
+    sd = synth_state_dict(small_shape(2, 2), seed=5, text=False)
+    x = synth_tiles(96, seed=123)
+    with torch.no_grad():
+        ref_f = O.encode_image(sd, x)
+    gen = torch.Generator().manual_seed(7)
+    u = torch.nn.functional.normalize(torch.randn(768, generator=gen), dim=0)
+    pairs = []
+    for t1 in text_bank[:8]:
+        pairs += [t1, torch.nn.functional.normalize(t1 + 3e-3 * u, dim=0)]
+    bank = torch.stack(pairs)
+    ref = ref_f @ bank.t()
+    ref_lab = ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    assert (margin < 3e-4).sum() > 20                      # the bank does produce near ties
+    for precision in ("comp", "strict"):
+        m = make_model(sd, precision)
+        sim, lab = m.similarity(m.encode_image(x.cuda()), bank.cuda(), mode="argmax")
+        err = (sim.cpu() - ref).abs().max().item()
+        differ = lab.cpu().long() != ref_lab
+        print(f"[near tie {precision}] max|dcos|={err:.2e}, {int(differ.sum())} of {len(x)} labels differ, median margin {margin.median():.2e}")
+        assert not (differ & (margin > 2 * err)).any()
+        if precision == "strict":
+            assert int(differ.sum()) <= 1
 
 
 # ------------------------------------------------------------------ similarity modes

@@ -8,7 +8,8 @@ from keep_amd.config import KEEPShape
 from keep_amd.synth import synth_prompts, synth_state_dict
 
 sd = synth_state_dict(KEEPShape(), seed=0)
-m = KEEPModel(); m.load_state_dict(sd); m.to("cuda:0")
+from keep_amd.synth import towers_of
+m = KEEPModel(towers=towers_of(sd)); m.load_state_dict(sd); m.to("cuda:0")
 for a in sys.argv[1:]:
     k, v = a.split("="); m.set_option(k, float(v))
 def wall(fn, n=30):

@@ -16,7 +16,8 @@ g = torch.Generator().manual_seed(3)
 txt = torch.nn.functional.normalize(torch.randn(64, 768, generator=g), dim=-1)
 with torch.no_grad():
     ref = O.encode_image(sd, x)
-m = KEEPModel()
+from keep_amd.synth import towers_of
+m = KEEPModel(towers=towers_of(sd))
 m.load_state_dict(sd)
 m.to("cuda:0")
 big = torch.randn(256, 3, 224, 224, device="cuda").to(torch.bfloat16)

@@ -5,15 +5,19 @@ set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof; rm -rf "$OUT"; mkdir -p "$OUT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/kt --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats -d /tmp/kt --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-configs --no-sustained \
     > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/kt.log"
 cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 # counters: their own passes, kernel-trace only (FETCH_SIZE and WRITE_SIZE do not share a pass)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown \
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown --no-configs --no-sustained \
       > /dev/null 2> "$OUT/pmc_$c.log"
 done
+# MFMA pipe utilisation of the same command (its own pass)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_MFMA --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown --no-configs --no-sustained \
+    > /dev/null 2> "$OUT/pmc_MFMA.log"
 cd "$REPO"
+python tools/pmc_summary.py "$(find /tmp/pmc_MFMA -name '*counter_collection.csv' | head -1)" > "$OUT/mfma_busy.txt" 2>&1
 python tools/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" \
                             "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" > /dev/null
 head -c 600 "$OUT/bench.json"; echo; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/hbm_traffic.json" | head -12

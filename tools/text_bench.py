@@ -8,7 +8,8 @@ from keep_amd.config import KEEPShape
 from keep_amd.synth import synth_prompts, synth_state_dict
 
 sd = synth_state_dict(KEEPShape(), seed=0)
-m = KEEPModel(); m.load_state_dict(sd); m.to("cuda:0")
+from keep_amd.synth import towers_of
+m = KEEPModel(towers=towers_of(sd)); m.load_state_dict(sd); m.to("cuda:0")
 def flops_at(T):       # 12 layers at sequence length T + pooler (SURVEY.md §8d formula, padded length = 256)
     H, I, L = 768, 3072, 12
     return L * (2 * T * H * 3 * H + 4 * T * T * H + 2 * T * H * H + 4 * T * H * I) + 2 * H * H
