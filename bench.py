@@ -312,6 +312,7 @@ def main():
         c5 = config5(model, dev)
         log("configs done")
 
+    line = None
     if rank == 0:
         tiles_per_s = world * B * args.steps / elapsed
         avg_ms = dom_ms / max(dom_n, 1)
@@ -363,9 +364,18 @@ def main():
             log("cpu baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline(sd)
             log("cpu baseline done")
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which a pipe only sees at exit: push it out first so that the JSON
+        # line is the LAST line on stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -287,59 +287,40 @@ void gemm_f16_v2_kernel(GemmParams p) {
         const int a_row = (wm * 128 + frow) * 16, w_row = (wn * 64 + frow) * 16;
         const int asc_off = 32768 + fhi * 512 + (wm * 32 + frow) * 4, wsc_off = 32768 + 1024 + fhi * 512 + ((wn >> 1) * 32 + frow) * 4;
         const int wsh = (wn & 1) * 16;
-        // Two MFMA groups per chunk, as in phase 1: group A = W_lo x A_hi, group B = W_hi x A_lo (8 instructions each).  The
-        // fragments of one group are fetched under the other group's MFMAs, the single barrier of a chunk sits between them.
-        uint4 ah[4], al[4], wh[2], wl[2];
-        int sah = 0, sal = 0, swh = 0, swl = 0;
-        auto read_a = [&](int c) {
+        // One step per chunk: fetch the 12 fragments + 4 scale dwords, issue the DMA of chunk c+3, 16 MFMAs, counted wait, barrier.
+        // The phase is bound by the LDS-DMA stream, like phase 1 (34 KiB per chunk against 64 KiB per K = 64 there, and it takes
+        // 0.53x the time): a two-group software pipeline of the MFMAs (fragments of one group fetched under the other's MFMAs,
+        // barrier in between) measured 20 % SLOWER with or without sched_barrier pins, with the DMA issued early or late --
+        // what counts is how long the DMA requests are in flight, and this order keeps three chunks outstanding the longest.
+#define KEEP_V8(V_) v8i{(int)(V_).x, (int)(V_).y, (int)(V_).z, (int)(V_).w, 0, 0, 0, 0}
+#define KEEP_MX(I, J) \
+            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah); \
+            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
+        for (int c = 0; c < NC; ++c) {
             const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
             const unsigned char* sa = sb + fhi * 8192;                  // this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31
             const unsigned char* sw = sb + 16384 + fhi * 8192;
+            uint4 ah[4], al[4], wh[2], wl[2];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) ah[jj] = *reinterpret_cast<const uint4*>(sa + a_row + jj * 512);
+            for (int jj = 0; jj < 4; ++jj) {
+                ah[jj] = *reinterpret_cast<const uint4*>(sa + a_row + jj * 512);
+                al[jj] = *reinterpret_cast<const uint4*>(sa + 4096 + a_row + jj * 512);
+            }
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) wl[ii] = *reinterpret_cast<const uint4*>(sw + 4096 + w_row + ii * 512);
-            sah = *reinterpret_cast<const int*>(sb + asc_off);
-            swl = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off + 256) >> wsh);
-        };
-        auto read_b = [&](int c) {
-            const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
-            const unsigned char* sa = sb + fhi * 8192;
-            const unsigned char* sw = sb + 16384 + fhi * 8192;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) al[jj] = *reinterpret_cast<const uint4*>(sa + 4096 + a_row + jj * 512);
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) wh[ii] = *reinterpret_cast<const uint4*>(sw + w_row + ii * 512);
-            sal = *reinterpret_cast<const int*>(sb + asc_off + 256);
-            swh = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off) >> wsh);
-        };
-#define KEEP_V8(V_) v8i{(int)(V_).x, (int)(V_).y, (int)(V_).z, (int)(V_).w, 0, 0, 0, 0}
-#define KEEP_MXA(I, J) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah);
-#define KEEP_MXB(I, J) acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
-#define KEEP_PIN2() __builtin_amdgcn_sched_barrier(0)
-        read_a(0);
-        for (int c = 0; c < NC; ++c) {
-            KEEP_MXA(0, 0) KEEP_MXA(0, 1) KEEP_MXA(0, 2) KEEP_MXA(0, 3)
-            KEEP_PIN2();
-            read_b(c);
-            KEEP_PIN2();
-            KEEP_MXA(1, 0) KEEP_MXA(1, 1) KEEP_MXA(1, 2) KEEP_MXA(1, 3)
-            KEEP_PIN2();
-            // chunk c+1 must have landed before anyone passes the barrier: chunks c+1, c+2 are outstanding here
-            if (c + 2 < NC) wait_vmcnt<G2>(); else wait_vmcnt<0>();
+            for (int ii = 0; ii < 2; ++ii) {
+                wh[ii] = *reinterpret_cast<const uint4*>(sw + w_row + ii * 512);
+                wl[ii] = *reinterpret_cast<const uint4*>(sw + 4096 + w_row + ii * 512);
+            }
+            const int sah = *reinterpret_cast<const int*>(sb + asc_off), sal = *reinterpret_cast<const int*>(sb + asc_off + 256);
+            const int swh = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off) >> wsh), swl = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off + 256) >> wsh);
+            if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));     // the stage chunk c-1 was read from
+            KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)
+            KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)
+            if (c + V2_NST2 - 1 < NC) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();          // chunk c+1 has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            KEEP_PIN2();
-            KEEP_MXB(0, 0) KEEP_MXB(0, 1) KEEP_MXB(0, 2) KEEP_MXB(0, 3)
-            KEEP_PIN2();
-            if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));    // overwrites the stage of chunk c-1
-            if (c + 1 < NC) read_a(c + 1);
-            KEEP_PIN2();
-            KEEP_MXB(1, 0) KEEP_MXB(1, 1) KEEP_MXB(1, 2) KEEP_MXB(1, 3)
         }
-#undef KEEP_PIN2
-#undef KEEP_MXA
-#undef KEEP_MXB
+#undef KEEP_MX
 #undef KEEP_V8
     }
 

@@ -62,6 +62,6 @@ def test_bench_distributed_leg_runs_on_nccl():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
                         "--no-cpu-baseline", "--no-breakdown", "--no-configs"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = json.loads(r.stdout.strip().splitlines()[-1])          # the JSON line is the last thing on stdout, after RCCL's banner
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert "RCCL" in line["config"]["exchange"]
