@@ -115,6 +115,16 @@ int keep_bert_layers(keep_handle* h);
 int keep_set_option(keep_handle* h, const char* name, double value);
 double keep_get_option(keep_handle* h, const char* name);
 
+/* ---- preprocessing on the device -----------------------------------------------------------------
+ * Replaces: transforms.Resize(224, BICUBIC) + CenterCrop((224,224))  (quick_start/keep_inference.py:88-90) for raw uint8
+ * RGB images [B,H,W,3] of one size.  The fixed-point windows / weights of Pillow's resample are built by the caller
+ * (keep_amd/preprocess.py: pil_bicubic_coeffs) -- bounds [out,2] = (first input index, count), weights [out,ksize] -- and the
+ * two integer passes run here, so the result is bit-identical to PIL's.  out: uint8 [B,size,size,3], ready for
+ * keep_encode_image(..., KEEP_PIX_U8_HWC, ...). */
+int keep_resize_crop_u8(keep_handle* h, const unsigned char* src, int64_t B, int64_t H, int64_t W, const int32_t* xbounds,
+                        const int32_t* xweights, int xksize, int64_t out_w, const int32_t* ybounds, const int32_t* yweights, int yksize,
+                        int64_t out_h, int64_t crop_left, int64_t crop_top, int64_t size, unsigned char* out, void* stream);
+
 /* Pre-allocate workspace for calls of up to `tiles` tiles and `prompts` x `seq` tokens. */
 int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq);
 int64_t keep_workspace_bytes(keep_handle* h);

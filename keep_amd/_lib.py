@@ -37,6 +37,7 @@ SIGNATURES = {
     "keep_workspace_bytes": (_i64, [_vp]),
     "keep_encode_image": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "keep_encode_text": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "keep_resize_crop_u8": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp]),
     "keep_token_error": (_i32, [_vp, _vp]),
     "keep_similarity": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp]),
     "keep_prompt_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),

@@ -175,6 +175,9 @@ int launch_sgemm_f32(const SgemmParams& p, hipStream_t s);
 // Row-wise helpers (rowops.hip)
 void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_lo,      // out in blk layout (KT = 24)
                    const float* cls, const float* pos, float* resid, int D, hipStream_t s);
+// Pillow-exact bicubic Resize + CenterCrop of raw uint8 HWC images (weights / windows from keep_amd/preprocess.py)
+void launch_resize_crop_u8(const unsigned char* src, int B, int H, int W, const int* xb, const int* xk, int xks, int col0, int ncols,
+                           const int* yb, const int* yk, int yks, int row0, int nrows, unsigned char* tmp, unsigned char* out, hipStream_t s);
 void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s);
 // row-major fp32 [M][K] -> blk-layout fp16 hi (+lo); rows M..pad are zero-filled
 void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hipStream_t s);

@@ -1119,6 +1119,27 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     return KEEP_OK;
 }
 
+int keep_resize_crop_u8(keep_handle* h, const unsigned char* src, int64_t B, int64_t H, int64_t W, const int32_t* xbounds, const int32_t* xweights,
+                        int xksize, int64_t out_w, const int32_t* ybounds, const int32_t* yweights, int yksize, int64_t out_h,
+                        int64_t crop_left, int64_t crop_top, int64_t size, unsigned char* out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!src || !xbounds || !xweights || !ybounds || !yweights || !out || B < 0 || H < 1 || W < 1 || xksize < 1 || yksize < 1)
+        return h->fail(KEEP_EINVAL, "bad resize arguments");
+    if (size < 1 || crop_left < 0 || crop_top < 0 || crop_left + size > out_w || crop_top + size > out_h)
+        return h->fail(KEEP_EINVAL, "crop window [%lld+%lld, %lld+%lld] outside the resized image %lldx%lld", (long long)crop_left, (long long)size,
+                       (long long)crop_top, (long long)size, (long long)out_w, (long long)out_h);
+    if (B == 0) return KEEP_OK;
+    KEEP_ON_DEVICE(h);
+    // the horizontally resized rows live in the arena; whatever runs next on this stream (e.g. the encode of the cropped tiles) is
+    // ordered behind the two kernels, so reusing the arena there is safe
+    const size_t tmp_bytes = align_up((size_t)B * H * size * 3);
+    int rc = ensure_arena(h, tmp_bytes);
+    if (rc) return rc;
+    launch_resize_crop_u8(src, (int)B, (int)H, (int)W, xbounds, xweights, xksize, (int)crop_left, (int)size, ybounds, yweights, yksize,
+                          (int)crop_top, (int)size, (unsigned char*)h->arena, out, (hipStream_t)stream);
+    return check_launch(h, "resize_crop_u8");
+}
+
 int keep_token_error(keep_handle* h, void* stream) {
     if (!h) return KEEP_EINVAL;
     KEEP_ON_DEVICE(h);

@@ -420,6 +420,50 @@ void bert_embed_ln_kernel(const int64_t* __restrict__ ids, const int64_t* __rest
     }
 }
 
+// ------------------------------------------------------------------ Resize(224, bicubic) + CenterCrop on raw uint8 tiles
+// Pillow's 8-bit resample (what torchvision's Resize runs on PIL inputs, keep_inference.py:88-90): 22-bit fixed-point weights
+// (built on the host in float64 exactly as libImaging does, keep_amd/preprocess.py), horizontal pass -> uint8 -> vertical
+// pass -> uint8; only the columns / rows that survive the centre crop are computed.  Bit-identical to PIL.
+__device__ __forceinline__ unsigned char clip8_fixed(int v) {
+    v >>= 22;
+    return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+// tmp[b][y][xx][c] = sum_x src[b][y][x0 + x][c] * k[x]     for xx in the cropped column range
+__global__ __launch_bounds__(256)
+void resize_h_u8_kernel(const unsigned char* __restrict__ src, int B, int H, int W, const int* __restrict__ bounds,
+                        const int* __restrict__ kk, int ksize, int col0, int ncols, unsigned char* __restrict__ tmp) {
+    const int64_t total = (int64_t)B * H * ncols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xx = (int)(i % ncols);
+        const int64_t row = i / ncols;                            // b * H + y
+        const int x0 = bounds[2 * (col0 + xx)], n = bounds[2 * (col0 + xx) + 1];
+        const int* k = kk + (int64_t)(col0 + xx) * ksize;
+        const unsigned char* s = src + (row * W + x0) * 3;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        for (int x = 0; x < n; ++x) { const int w = k[x]; a0 += s[3 * x] * w; a1 += s[3 * x + 1] * w; a2 += s[3 * x + 2] * w; }
+        unsigned char* d = tmp + i * 3;
+        d[0] = clip8_fixed(a0); d[1] = clip8_fixed(a1); d[2] = clip8_fixed(a2);
+    }
+}
+// out[b][yy][xx][c] = sum_y tmp[b][y0 + y][xx][c] * k[y]    for yy in the cropped row range
+__global__ __launch_bounds__(256)
+void resize_v_u8_kernel(const unsigned char* __restrict__ tmp, int B, int H, int ncols, const int* __restrict__ bounds,
+                        const int* __restrict__ kk, int ksize, int row0, int nrows, unsigned char* __restrict__ out) {
+    const int64_t total = (int64_t)B * nrows * ncols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int xx = (int)(i % ncols);
+        const int yy = (int)((i / ncols) % nrows);
+        const int b = (int)(i / ((int64_t)ncols * nrows));
+        const int y0 = bounds[2 * (row0 + yy)], n = bounds[2 * (row0 + yy) + 1];
+        const int* k = kk + (int64_t)(row0 + yy) * ksize;
+        const unsigned char* s = tmp + (((int64_t)b * H + y0) * ncols + xx) * 3;
+        int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+        for (int y = 0; y < n; ++y) { const int w = k[y]; const unsigned char* p = s + (int64_t)y * ncols * 3; a0 += p[0] * w; a1 += p[1] * w; a2 += p[2] * w; }
+        unsigned char* d = out + i * 3;
+        d[0] = clip8_fixed(a0); d[1] = clip8_fixed(a1); d[2] = clip8_fixed(a2);
+    }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst, int rows, int D) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * D) return;
@@ -480,6 +524,12 @@ void launch_im2col(const void* pixels, int dtype, int B, f16* out_hi, f16* out_l
     hipLaunchKernelGGL(cls_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cls, pos, resid, B, D, 197);
 }
 
+void launch_resize_crop_u8(const unsigned char* src, int B, int H, int W, const int* xb, const int* xk, int xks, int col0, int ncols,
+                           const int* yb, const int* yk, int yks, int row0, int nrows, unsigned char* tmp, unsigned char* out, hipStream_t s) {
+    auto blocks = [](int64_t n) { int64_t b = (n + 255) / 256; return (unsigned)(b > 65536 ? 65536 : (b < 1 ? 1 : b)); };
+    hipLaunchKernelGGL(resize_h_u8_kernel, dim3(blocks((int64_t)B * H * ncols)), dim3(256), 0, s, src, B, H, W, xb, xk, xks, col0, ncols, tmp);
+    hipLaunchKernelGGL(resize_v_u8_kernel, dim3(blocks((int64_t)B * nrows * ncols)), dim3(256), 0, s, tmp, B, H, ncols, yb, yk, yks, row0, nrows, out);
+}
 void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;

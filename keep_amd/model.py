@@ -277,6 +277,46 @@ class KEEPModel:
         return out if src_dev == self._device else out.to(src_dev)
 
     @torch.no_grad()
+    def resize_crop_uint8(self, images_u8: torch.Tensor, size: int = 224) -> torch.Tensor:
+        """Raw RGB images, uint8 [B,H,W,3] of ONE size -> uint8 [B,size,size,3]: the reference transform's
+        ``Resize(size, BICUBIC)`` + ``CenterCrop((size, size))`` (keep_inference.py:88-90) on the device, bit-identical to the
+        PIL code path torchvision runs.  Feed the result to :meth:`encode_image_uint8`."""
+        from .preprocess import pil_bicubic_coeffs, resize_output_size
+        self._ready_device()
+        x = images_u8
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError(f"expected uint8 [B,H,W,3], got {x.dtype} {tuple(x.shape)}")
+        B, H, W, _ = x.shape
+        ow, oh = resize_output_size(W, H, size)
+        if ow < size or oh < size:
+            raise ValueError(f"resized image {ow}x{oh} is smaller than the {size}-pixel crop (torchvision would zero-pad: not supported on the device)")
+        key = (W, H, size)
+        if getattr(self, "_resize_cache", None) is None:
+            self._resize_cache = {}
+        if key not in self._resize_cache:             # float64 table construction as in libImaging; a few ms, once per image size
+            xb, xk, xks = pil_bicubic_coeffs(W, ow)
+            yb, yk, yks = pil_bicubic_coeffs(H, oh)
+            dev = lambda a: torch.from_numpy(a).to(self._device).contiguous()
+            self._resize_cache[key] = (dev(xb), dev(xk), xks, dev(yb), dev(yk), yks)
+        xb, xk, xks, yb, yk, yks = self._resize_cache[key]
+        left, top = int(round((ow - size) / 2.0)), int(round((oh - size) / 2.0))
+        src_dev = x.device
+        xd = x.to(self._device, non_blocking=True).contiguous()
+        out = torch.empty((B, size, size, 3), dtype=torch.uint8, device=self._device)
+        _lib.check(self._handle, _lib.load().keep_resize_crop_u8(self._handle, _ptr(xd), B, H, W, _ptr(xb), _ptr(xk), xks, ow, _ptr(yb), _ptr(yk), yks, oh,
+                                                                 left, top, size, _ptr(out), _stream(self._device)), "resize_crop_u8")
+        return out if src_dev == self._device else out.to(src_dev)
+
+    @torch.no_grad()
+    def encode_image_raw(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] raw tiles of any (common) size -> [B,768]: the whole reference transform + ``encode_image`` on the
+        device (resize + crop bit-identical to PIL, /255 and mean/std fused into the first encoder kernel)."""
+        self._ready()
+        dev_in = images_u8.device
+        out = self.encode_image_uint8(self.resize_crop_uint8(images_u8.to(self._device)))
+        return out if dev_in == self._device else out.to(dev_in)
+
+    @torch.no_grad()
     def encode_text(self, text_inputs: Mapping[str, torch.Tensor]) -> torch.Tensor:
         """keep_inference.py:60-62: normalize(text(**inputs).pooler_output, dim=-1) -> [P, 768] fp32."""
         self._ready()

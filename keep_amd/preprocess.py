@@ -54,3 +54,77 @@ def preprocess(img: Union[str, Image.Image], size: int = 224) -> torch.Tensor:
 
 def preprocess_batch(images: Iterable[Union[str, Image.Image]], size: int = 224) -> torch.Tensor:
     return torch.stack([preprocess(i, size) for i in images])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Pillow's 8-bit bicubic resample, restated (what ``Image.resize(..., BICUBIC)`` -- and therefore torchvision's
+# ``Resize`` on PIL inputs, keep_inference.py:89 -- computes): per output coordinate a window of input pixels
+# [xmin, xmin + n) with weights bicubic((x - center + 0.5) / filterscale) normalised to 1 and rounded to 22-bit fixed point
+# (the support widens with the scale factor when shrinking = antialiasing); horizontal pass, uint8 rounding, vertical pass.
+# The coefficient tables are built here in float64 exactly as libImaging does; the two integer passes run on the device
+# (keep_resize_crop_u8), so the on-device result is bit-identical to PIL's (tests/test_preprocess.py).
+# ------------------------------------------------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size: int, out_size: int):
+    """-> (bounds int32 [out,2] = (first input index, count), weights int32 [out,ksize], ksize)."""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.array([_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)], dtype=np.float64)
+        ww = w.sum()
+        if ww != 0.0:
+            w = w / ww
+        fixed = w * (1 << PIL_PRECISION_BITS)
+        kk[xx, :xmax] = np.where(fixed < 0, (fixed - 0.5).astype(np.int64), (fixed + 0.5).astype(np.int64))   # C cast: toward zero
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def resize_output_size(w: int, h: int, size: int = 224):
+    """torchvision ``Resize(size)``: shorter side -> size, the other int(size * long / short); identity when already there."""
+    if (w <= h and w == size) or (h <= w and h == size):
+        return w, h
+    return (size, int(size * h / w)) if w < h else (int(size * w / h), size)
+
+
+def resize_bicubic_u8_numpy(arr: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """The two integer passes on the host (test restatement of the device kernels): uint8 [H,W,C] -> uint8 [out_h,out_w,C]."""
+    h, w, _ = arr.shape
+    src = arr.astype(np.int64)
+    if out_w != w:
+        bounds, kk, _ = pil_bicubic_coeffs(w, out_w)
+        tmp = np.empty((h, out_w, arr.shape[2]), dtype=np.int64)
+        for xx in range(out_w):
+            x0, n = bounds[xx]
+            acc = (src[:, x0:x0 + n, :] * kk[xx, :n, None].astype(np.int64)).sum(axis=1) + (1 << (PIL_PRECISION_BITS - 1))
+            tmp[:, xx, :] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        src = tmp
+    if out_h != h:
+        bounds, kk, _ = pil_bicubic_coeffs(h, out_h)
+        out = np.empty((out_h, src.shape[1], arr.shape[2]), dtype=np.int64)
+        for yy in range(out_h):
+            y0, n = bounds[yy]
+            acc = (src[y0:y0 + n, :, :] * kk[yy, :n, None, None].astype(np.int64)).sum(axis=0) + (1 << (PIL_PRECISION_BITS - 1))
+            out[yy] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        src = out
+    return src.astype(np.uint8)

@@ -27,6 +27,46 @@ def test_resize_then_crop_shapes():
         assert preprocess(Image.fromarray(arr)).shape == (3, 224, 224)
 
 
+def test_resample_restatement_is_pil_bit_for_bit():
+    """keep_amd.preprocess restates Pillow's 8-bit bicubic resample (float64 window construction, 22-bit weights, two integer
+    passes): up- and down-scaling, both orientations, the identity case."""
+    from keep_amd.preprocess import resize_bicubic_u8_numpy, resize_output_size
+    rng = np.random.default_rng(1)
+    for w, h in ((512, 300), (300, 512), (1024, 1024), (256, 256), (100, 180), (231, 224), (897, 673)):
+        arr = (rng.random((h, w, 3)) * 255).astype(np.uint8)
+        ow, oh = resize_output_size(w, h)
+        ref = np.asarray(Image.fromarray(arr).resize((ow, oh), Image.BICUBIC))
+        assert np.array_equal(resize_bicubic_u8_numpy(arr, ow, oh), ref), (w, h)
+
+
+@pytest.mark.gpu
+def test_resize_crop_on_device_is_pil_bit_for_bit(golden_dir):
+    """Row f4: Resize(224, bicubic) + CenterCrop on the device for raw uint8 tiles == the PIL path of keep_amd.preprocess
+    (uint8 equality), and encode_image_raw == encode_image(preprocess(...)) to fp32 rounding."""
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.preprocess import _center_crop, _resize_shorter_side
+    from keep_amd.synth import synth_state_dict
+    sd = synth_state_dict(small_shape(2, 1), seed=8, text=False)
+    m = KEEPModel(precision="strict", towers=("image",))
+    m.load_state_dict(sd)
+    m.to("cuda:0")
+    rng = np.random.default_rng(2)
+    for w, h, b in ((512, 300, 3), (300, 512, 2), (1024, 1024, 2), (256, 256, 5), (225, 224, 1), (897, 673, 1)):
+        arr = (rng.random((b, h, w, 3)) * 255).astype(np.uint8)
+        ref = np.stack([np.asarray(_center_crop(_resize_shorter_side(Image.fromarray(a), 224), 224)) for a in arr])
+        got = m.resize_crop_uint8(torch.from_numpy(arr).cuda())
+        assert got.shape == (b, 224, 224, 3) and np.array_equal(got.cpu().numpy(), ref), (w, h)
+    imgs = [Image.fromarray(a) for a in arr]
+    feats = m.encode_image_raw(torch.from_numpy(arr))
+    ref_feats = m.encode_image(preprocess_batch(imgs))
+    assert (feats - ref_feats).abs().max() < 2e-6
+    tif = np.asarray(Image.open(os.path.join(golden_dir, "example.tif")).convert("RGB"))[None]
+    assert (m.encode_image_raw(torch.from_numpy(tif.copy())) - m.encode_image(preprocess(os.path.join(golden_dir, "example.tif"))[None])).abs().max() < 2e-6
+    with pytest.raises(ValueError):
+        m.resize_crop_uint8(torch.zeros(1, 10, 10, 4, dtype=torch.uint8))
+
+
 @pytest.mark.gpu
 def test_quick_start_plumbing_matches_oracle(golden_dir):
     """BASELINE config 1: one tile x three prompts through both towers and the similarity."""

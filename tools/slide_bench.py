@@ -19,7 +19,12 @@ def t(name, f, n=5):
     print(f"{name:58s} {dt*1e3:9.2f} ms", flush=True); return r
 fn = t("normalize features [100k,768]", lambda: wsi._normalized(m, feats))
 bank = torch.stack([c.t() for c in cls]).reshape(K * C, D).contiguous()
-sc = t(f"prompt_scores: [100k,768]x[768,{K*C}] + top-2 scores (1.09 TFLOP fp32)", lambda: wsi.prompt_scores(m, fn, cls, pre_normalized=True), 3)
+for mode, name in ((1, "fused, fp16 + MX-fp4 corrections, top-2 in registers"), (2, "fused, three fp16 passes"), (0, "unfused: fp32 MFMA GEMM, logits through HBM")):
+    m.set_option("fused_screening", mode)
+    sc_m = t(f"prompt_scores [100k,768]x[768,{K*C}] (1.09 TFLOP): {name}", lambda: wsi.prompt_scores(m, fn, cls, pre_normalized=True), 3)
+    if mode == 1: sc = sc_m
+    else: print(f"    max |score - fused score| = {(sc_m - sc).abs().max().item():.2e}")
+m.set_option("fused_screening", 1)
 ens = t("zero_shot_prompt_select (scores + sort + merge top 50)", lambda: wsi.zero_shot_prompt_select(m, cls, feats, 50), 3)
 pr = t("probabilities softmax(10 cos) [100k,4]", lambda: wsi._probs(m, ens, feats))
 t("refine (coordinate hash + 2x2 neighbour mean)", lambda: wsi.refine(m, pr, coords, 256, True))
