@@ -87,8 +87,8 @@ int keep_bert_layers(keep_handle* h);
 /* ---- options ----------------------------------------------------------------------------------
  *   "precision"       KEEP_PREC_COMP (default) | KEEP_PREC_FP16 | KEEP_PREC_STRICT
  *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
- *   "comp_full_blocks" KEEP_PREC_COMP: ViT blocks whose qkv / attention / proj run as split products (default 2)
- *   "comp_mlp_blocks"  KEEP_PREC_COMP: ViT blocks whose fc1 / fc2 run as compensated products (default 12)
+ *   "comp_full_blocks" KEEP_PREC_COMP: ViT blocks whose qkv / attention / proj run as split products (default 1)
+ *   "comp_mlp_blocks"  KEEP_PREC_COMP: ViT blocks whose fc1 / fc2 run as compensated products (default 8)
  *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
  *   "fused_screening"  keep_prompt_scores with C in {2, 4}: 1 (default) one compensated GEMM with the top-2 score taken in the
  *                     accumulator registers (no logits in HBM) | 2 the same with three fp16 passes | 0 chunked fp32 GEMM + reduction

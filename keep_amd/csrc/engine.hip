@@ -82,8 +82,10 @@ struct keep_handle {
     KeepTune tune;               // kernel selection (travels in the launch parameter blocks; nothing is process-wide)
     int precision = KEEP_PREC_COMP;
     int strict_blocks = 0;       // first n blocks / layers as full hi/lo split products (any mode)
-    int comp_full_blocks = 2;    // KEEP_PREC_COMP: first n ViT blocks run qkv / attention / proj as split products as well
-    int comp_mlp_blocks = 12;    // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
+    // Defaults from measurements on the 262 144 cosines of BASELINE config 3 (profiles/r02_precision_modes.txt): (1, 8) gives
+    // max |dcos| 7.6-7.9e-5 (21-27 % head-room on fresh tiles / other weights), (2, 12) 7.1e-5 at -8 % throughput, (1, 6) 8.5e-5.
+    int comp_full_blocks = 1;    // KEEP_PREC_COMP: first n ViT blocks run qkv / attention / proj as split products as well
+    int comp_mlp_blocks = 8;     // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
     int fused_screening = 1;     // keep_prompt_scores: 1 fused compensated GEMM (default) | 2 fused 3-pass split GEMM | 0 logits through HBM (any C)
     int comp_min_tiles = 32;     // lanes with fewer tiles take the split product where a compensated one is asked for (small-M kernels)
     int max_tiles = 256;
@@ -912,7 +914,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "gemm_impl") {
         bool ok = v == 0 || v == 128 || v == 256;
 #ifdef KEEP_EXPERIMENTS
-        ok = ok || v == 1 || v == 3 || v == 2128 || v == 3256 || v == 4256;
+        ok = ok || v == 1 || v == 3 || v == 2128 || v == 3256 || v == 4256 || v == 5256;
 #endif
         if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256; experiment builds add 1, 3, 2128, 3256, 4256)", v);
         t.gemm_impl = v;

@@ -553,6 +553,7 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
     // measured-negative variants, kept as the record of the experiments: 96 KiB ring; 4 waves x 128x128
     // (11 % slower end to end: the LDS-DMA issue cost is exposed with one wave per SIMD); 256x128 / 4 waves / two workgroups per CU
     if (variant == 3256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 3>(p, epi, s);
+    if (variant == 5256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 5>(p, epi, s);      // 160 KiB ring: every byte of LDS
     if (variant == 4256 && p.N % 256 == 0) return launch_v2<256, 2, 2, 4>(p, epi, s);
     if (variant == 2128 && p.N % 128 == 0) return launch_v2<128, 2, 2, 3>(p, epi, s);
 #endif
