@@ -142,7 +142,10 @@ struct keep_handle {
         return 0;
     }
     // the text tower is 1 % of a slide's work: in the compensated mode it simply runs split products throughout
-    bool txt_split(int l) const { return precision != KEEP_PREC_FP16 || l < strict_blocks; }
+    // (the split attention kernel covers T <= 256, the reference's max_length; in the compensated mode longer sequences fall back to
+    // single fp16 passes instead of failing -- strict mode and strict_blocks reject them)
+    bool txt_split(int l, int T) const { return precision == KEEP_PREC_STRICT || l < strict_blocks || (precision == KEEP_PREC_COMP && T <= 256); }
+    bool txt_must_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
     bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
     bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 64 == 0)
     bool any_comp() const { return precision == KEEP_PREC_COMP && comp_mlp_blocks > 0 && vit_has_q; }
@@ -523,8 +526,8 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
     }
     for (int l = 0; l < h->bert_layers; ++l) {
         const BertLayer& b = h->blayers[l];
-        const bool sp = h->txt_split(l);
-        const bool sp_next = (l + 1 < h->bert_layers) && h->txt_split(l + 1);
+        const bool sp = h->txt_split(l, T);
+        const bool sp_next = (l + 1 < h->bert_layers) && h->txt_split(l + 1, T);
         {
             Scope sc(h, T_TXT_QKV, s);
             GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
@@ -1091,7 +1094,7 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     if (!h->finalized || !h->bert_layers) return h->fail(KEEP_ESTATE, "text tower not loaded / finalised");
     if (!ids || !out || P < 0 || T < 1) return h->fail(KEEP_EINVAL, "null pointer or bad shape");
     if (T > h->bert_maxpos) return h->fail(KEEP_EINVAL, "sequence length %lld exceeds max_position_embeddings %d", (long long)T, h->bert_maxpos);
-    if (T > 512 || (h->any_split() && T > 256)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
+    if (T > 512 || (h->txt_must_split() && T > 256)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
     if (P == 0) return KEEP_OK;
     KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;

@@ -150,6 +150,10 @@ def test_long_and_single_inputs(small, text_bank):
     ms = make_model(small, "strict")
     with pytest.raises(ValueError):
         ms.encode_text(toks)                      # strict mode supports T <= 256
+    # the default mode does not fail beyond the reference's max_length of 256: it falls back to single fp16 passes there
+    mc = make_model(small, "comp")
+    assert (mc.encode_text(toks) @ text_bank.t() - ref @ text_bank.t()).abs().max() < FP16_TOL
+    assert (mc.encode_text(one) @ text_bank.t() - ref1 @ text_bank.t()).abs().max() < FP16_TOL
 
 
 def test_forward_and_errors(small):
