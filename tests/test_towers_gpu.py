@@ -239,6 +239,25 @@ def test_splitk_path_matches_big_kernel(small, text_bank):
         assert ((a_img.cpu() - ref) @ text_bank.t()).abs().max() < tol(precision)
 
 
+def test_options_belong_to_their_handle(small):
+    """Kernel-selection options are per handle (there is no process-wide kernel state): pinning model A to the 256x256 kernel
+    must not change what model B computes, and vice versa."""
+    x = synth_tiles(1, seed=171).cuda()                      # 197 rows: the default engine takes the register-direct split-K kernel
+    b = make_model(small, "fp16")
+    ref_b = b.encode_image(x)
+    a = make_model(small, "fp16")
+    for k in ("gemm_skinny_m", "gemm_splitk_tiles", "sgemv_m"):
+        a.set_option(k, 0)
+    out_a = a.encode_image(x)
+    assert torch.equal(b.encode_image(x), ref_b)             # B is untouched by A's options
+    a2 = make_model(small, "fp16")
+    for k in ("gemm_skinny_m", "gemm_splitk_tiles", "sgemv_m"):
+        a2.set_option(k, 0)
+    assert torch.equal(a2.encode_image(x), out_a)            # and A's path is a property of A's options alone
+    assert not torch.equal(out_a, ref_b)                     # (the two paths sum K in different orders: equal only to rounding)
+    assert (out_a - ref_b).abs().max() < 2e-4
+
+
 def test_graph_replay_is_bit_identical(small):
     """Launch-bound calls (<= 1024 rows) are captured once and replayed as a hipGraph: same kernels, same bits; a changed
     option or reloaded weights must invalidate the captured graph."""

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Per-workgroup phase timeline of the attention kernel (shader clocks): staging (K by LDS-DMA, V^T through registers)
-vs compute (S^T, softmax, O^T) for the ViT-L shape, 128 tiles x 16 heads."""
+vs compute (S^T, softmax, O^T) for the ViT-L shape, 128 tiles x 16 heads.
+
+Needs a diagnostics build of the library (the timing / ablation hooks are compiled out of the product .so):
+    KEEP_BUILD_DEFINES="-DKEEP_DIAGNOSTICS" KEEP_BUILD_OUT=libkeep_hip_diag.so python -m keep_amd.build
+    KEEP_HIP_LIB=$PWD/keep_amd/libkeep_hip_diag.so python tools/attn_timeline.py
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

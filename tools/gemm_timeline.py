@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase timeline of the 256x256 GEMM (shader clocks) for the ViT-L shapes."""
+"""Per-workgroup phase timeline of the 256x256 GEMM (shader clocks) for the ViT-L shapes.
+
+Needs a diagnostics build of the library (the timing / ablation hooks are compiled out of the product .so):
+    KEEP_BUILD_DEFINES="-DKEEP_DIAGNOSTICS" KEEP_BUILD_OUT=libkeep_hip_diag.so python -m keep_amd.build
+    KEEP_HIP_LIB=$PWD/keep_amd/libkeep_hip_diag.so python tools/gemm_timeline.py
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
