@@ -215,6 +215,8 @@ void launch_top2_slots_reduce(const float* partial, int nslots, int kpad, int K,
 void launch_scale_vec(const float* in, int n, float f, float* out, hipStream_t s);
 int launch_sim_small(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax,
                      hipStream_t s);            // 0 handled, -1 not eligible (P > 8, D not 768/1024)
+int launch_sim_mid(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax,
+                   hipStream_t s);              // 9 <= P <= 64: fused fp32-MFMA similarity + argmax / softmax; 0 handled, -1 not eligible
 void launch_diag_rank(const float* sim, int rows, int n_img, const int* target, int row0, int* rank, hipStream_t s);
 void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
                    unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s);

@@ -1179,6 +1179,8 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
     Scope sc(h, T_SIM, s);
     if (h->tune.sgemv_m > 0 && launch_sim_small(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
         return check_launch(h, "similarity");
+    if (h->tune.sgemv_m > 0 && launch_sim_mid(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
+        return check_launch(h, "similarity");
     float* logits = (float*)out;
     const bool need_tmp = (mode == KEEP_SIM_ARGMAX && !out) || mode == KEEP_SIM_SOFTMAX_F16 || mode == KEEP_SIM_TOP2SCORE;
     const int nb = (int)((N + 255) / 256);

@@ -210,8 +210,112 @@ void sim_small_kernel(const float* __restrict__ img, const float* __restrict__ t
     }
 }
 
+// ---- tile x prompt similarity for 9..64 prompts (BASELINE config 3: 4096 tiles x 64 prompts, sim matrix + argmax) --------------
+// The 128x128 fp32-MFMA GEMM tile leaves most of the chip idle at this shape (64 columns = half a tile wide, 32 workgroups for
+// 4096 rows) and needs a second kernel for the argmax.  Here a workgroup owns 64 tile rows x all prompts: each wave 16 rows x NC
+// 16-column tiles on v_mfma_f32_16x16x4_f32 (exact f32 FMA chain), the prompt vectors staged through LDS 16 k at a time (double
+// buffered, one barrier per block), the tile rows streamed straight from HBM, and the row argmax / softmax taken on the
+// accumulators (4 rows x NC columns per lane, then 4 shuffle steps across the 16 lanes of a row).
+template <int NC>
+__global__ __launch_bounds__(256)
+void sim_mid_kernel(const float* __restrict__ img, const float* __restrict__ txt, int N, int P, int D, float scale, int mode,
+                    float* __restrict__ out_f32, f16* __restrict__ out_f16, int32_t* __restrict__ amax) {
+    __shared__ f32x4 sB[2][4][NC * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int row_base = blockIdx.x * 64 + wave * 16;
+    const int arow = min(row_base + j, N - 1);
+    const float* ap = img + (int64_t)arow * D + kq * 4;
+    const bool stager = tid < NC * 64;                       // one float4 of one prompt per thread and block
+    const int bcol = tid >> 2, bq = tid & 3;
+    const float* bp = txt + (int64_t)min(bcol, P - 1) * D + bq * 4;
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nblk = D >> 4;
+    f32x4 a_next = *reinterpret_cast<const f32x4*>(ap), b_next = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stager) b_next = *reinterpret_cast<const f32x4*>(bp);
+    for (int kb = 0; kb < nblk; ++kb) {
+        if (stager) sB[kb & 1][bq][bcol] = b_next;
+        const f32x4 a = a_next;
+        __syncthreads();
+        if (kb + 1 < nblk) {
+            a_next = *reinterpret_cast<const f32x4*>(ap + (kb + 1) * 16);
+            if (stager) b_next = *reinterpret_cast<const f32x4*>(bp + (kb + 1) * 16);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const f32x4 b = sB[kb & 1][kq][c * 16 + j];
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc[c], 0, 0, 0);
+        }
+    }
+    // lane (j, kq) holds rows row_base + kq*4 + r (r = 0..3) at columns c*16 + j
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row_base + kq * 4 + r;
+        const bool rok = row < N;
+        float x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c] = acc[c][r] * scale;
+        if (mode == KEEP_SIM_RAW || mode == KEEP_SIM_ARGMAX) {
+            if (out_f32 && rok) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) if (c * 16 + j < P) out_f32[(int64_t)row * P + c * 16 + j] = x[c];
+            }
+            if (mode == KEEP_SIM_ARGMAX) {
+                float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) if (c * 16 + j < P && x[c] > bv) { bv = x[c]; bi = c * 16 + j; }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {                      // first maximum wins, as torch.argmax
+                    const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (j == 0 && rok) amax[row] = bi;
+            }
+        } else {                                                        // softmax(scale * cos), arithmetic as row_softmax_kernel
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) if (c * 16 + j < P) mx = fmaxf(mx, x[c]);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float e[NC], sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { e[c] = (c * 16 + j < P) ? expf(x[c] - mx) : 0.f; sum += e[c]; }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+            const float inv = 1.0f / sum;
+            if (rok) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) if (c * 16 + j < P) {
+                    if (mode == KEEP_SIM_SOFTMAX) out_f32[(int64_t)row * P + c * 16 + j] = e[c] * inv;
+                    else out_f16[(int64_t)row * P + c * 16 + j] = (f16)(e[c] * inv);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace keepk
 using namespace keepk;
+
+// 9..64 prompts: returns 0 when handled, -1 when the shape is left to the GEMM path
+int launch_sim_mid(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax, hipStream_t s) {
+    if (P <= 8 || P > 64 || D % 16 || N < 1) return -1;
+    if (mode != KEEP_SIM_RAW && mode != KEEP_SIM_ARGMAX && mode != KEEP_SIM_SOFTMAX && mode != KEEP_SIM_SOFTMAX_F16) return -1;
+    float* of = (mode == KEEP_SIM_SOFTMAX_F16) ? nullptr : (float*)out;
+    f16* oh = (mode == KEEP_SIM_SOFTMAX_F16) ? (f16*)out : nullptr;
+    dim3 g((N + 63) / 64), b(256);
+    const int nc = (P + 15) / 16;
+    if (nc == 1) hipLaunchKernelGGL(sim_mid_kernel<1>, g, b, 0, s, img, txt, N, P, D, scale, mode, of, oh, amax);
+    else if (nc == 2) hipLaunchKernelGGL(sim_mid_kernel<2>, g, b, 0, s, img, txt, N, P, D, scale, mode, of, oh, amax);
+    else if (nc == 3) hipLaunchKernelGGL(sim_mid_kernel<3>, g, b, 0, s, img, txt, N, P, D, scale, mode, of, oh, amax);
+    else hipLaunchKernelGGL(sim_mid_kernel<4>, g, b, 0, s, img, txt, N, P, D, scale, mode, of, oh, amax);
+    return 0;
+}
 
 // returns 0 when handled, -1 when the shape is left to the GEMM path
 int launch_sim_small(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax,

@@ -522,6 +522,37 @@ def test_near_tie_argmax(text_bank):
 
 
 # ------------------------------------------------------------------ similarity modes
+@pytest.mark.parametrize("N,P", [(1, 9), (63, 16), (64, 17), (1000, 40), (4096, 64), (130, 64)])
+def test_similarity_9_to_64_prompts_fused_kernel(N, P):
+    """The config-3 shape (up to 64 prompts): fused fp32-MFMA similarity + argmax / softmax kernel, ragged row and column
+    counts, ties resolved like torch.argmax (first maximum), equal to the plain GEMM path to fp32 rounding."""
+    m = KEEPModel()
+    g = torch.Generator().manual_seed(N * 100 + P)
+    img = torch.nn.functional.normalize(torch.randn(N, 768, generator=g), dim=-1)
+    txt = torch.nn.functional.normalize(torch.randn(P, 768, generator=g), dim=-1)
+    txt[P - 1] = txt[2]                                     # a tie between column 2 and the last column (different lanes / tiles)
+    ref = O.similarity(img, txt)
+    raw = m.similarity(img, txt).cpu()
+    assert (raw - ref).abs().max() < 1e-6
+    sim, lab = m.similarity(img, txt, scale=25.0, mode="argmax")
+    assert (sim.cpu() - 25.0 * ref).abs().max() < 3e-5
+    got, exp = lab.cpu().long(), O.sim_argmax(ref).long()
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-6                 # rows whose maximum is unique beyond fp32 rounding
+    assert torch.equal(got[clear], exp[clear])
+    tied = ref.argmax(1) == 2                                # rows won by the duplicated prompt: the lower index must be reported
+    assert (got[tied] == 2).all() and not (got == P - 1).any()
+    sm = m.similarity(img, txt, scale=10.0, mode="softmax").cpu()
+    assert (sm - O.sim_softmax(ref, 10.0)).abs().max() < 1e-6 and (sm.sum(1) - 1).abs().max() < 1e-5
+    sm16 = m.similarity(img, txt, scale=10.0, mode="softmax_f16")
+    assert sm16.dtype == torch.float16 and (sm16.float().cpu() - O.sim_softmax(ref, 10.0)).abs().max() < 6e-4
+    m.set_option("sgemv_m", 0)                               # plain path: 128x128 fp32 GEMM + row kernels
+    assert (m.similarity(img, txt).cpu() - raw).abs().max() < 1e-6
+    _, lab2 = m.similarity(img, txt, scale=25.0, mode="argmax")
+    assert torch.equal(lab2.cpu().long()[clear], exp[clear])
+
+
+
 def test_similarity_modes():
     m = KEEPModel()
     g = torch.Generator().manual_seed(5)
