@@ -146,6 +146,10 @@ int keep_encode_text(keep_handle* h, const int64_t* input_ids, const int64_t* to
 /* 1 if any token / type id of the most recent keep_encode_text on `stream` was out of range (the
  * kernel clamps it; the reference's nn.Embedding would raise IndexError).  Synchronises `stream`. */
 int keep_token_error(keep_handle* h, void* stream);
+/* The same without a host synchronisation: enqueues a copy of the flag (0 / 1) into `host_flag` (pinned host memory owned by the
+ * caller) behind the work already on `stream`; the caller reads it once the stream has passed that point (event, or its next
+ * synchronisation).  This is how the reference's CUDA path reports an out-of-range index too: asynchronously. */
+int keep_token_error_async(keep_handle* h, int32_t* host_flag, void* stream);
 
 /* Replaces: `img_feature @ text_feature.T` (keep_inference.py:104), `image_features @ cls`
  * (WSI_evaluation/utils.py:128) and the softmax / top-2 score that follow it in the WSI scripts.

@@ -39,6 +39,7 @@ SIGNATURES = {
     "keep_encode_text": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "keep_resize_crop_u8": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp]),
     "keep_token_error": (_i32, [_vp, _vp]),
+    "keep_token_error_async": (_i32, [_vp, _vp, _vp]),
     "keep_similarity": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp]),
     "keep_prompt_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "keep_group_argmax": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),

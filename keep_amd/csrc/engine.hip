@@ -1166,6 +1166,13 @@ int keep_token_error(keep_handle* h, void* stream) {
     return flag ? 1 : 0;
 }
 
+int keep_token_error_async(keep_handle* h, int32_t* host_flag, void* stream) {
+    if (!h || !host_flag) return KEEP_EINVAL;
+    KEEP_ON_DEVICE(h);
+    HIPCHK(h, hipMemcpyAsync(host_flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return KEEP_OK;
+}
+
 int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t N, int64_t P, int64_t D, float scale, int mode,
                     void* out, int32_t* argmax_out, void* stream) {
     if (!h) return KEEP_EINVAL;

@@ -59,7 +59,12 @@ class KEEPModel:
         self.towers = tuple(towers)
         if not self.towers or any(t not in ("image", "text") for t in self.towers):
             raise ValueError(f"towers must be a non-empty subset of ('image', 'text'), got {towers!r}")
-        self.check_token_ids = True
+        # out-of-range token ids raise IndexError, as nn.Embedding does.  True: checked before encode_text returns (one host
+        # synchronisation per call); "lazy": the flag is copied back asynchronously and the error is raised by the NEXT engine call
+        # or by check_errors() -- no synchronisation, which is also how the reference's CUDA path reports it (device-side assert);
+        # False: never checked.  The reference's WSI scripts make thousands of one-prompt calls, so the default is "lazy".
+        self.check_token_ids = "lazy"
+        self._pending_token_check = None
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
 
@@ -229,6 +234,7 @@ class KEEPModel:
         return self
 
     def _ready(self):
+        self.check_errors(wait=False)
         if not self._loaded:
             if self._host_sd is not None:
                 self.to("cuda")            # reference scripts call .to(device) themselves; be lenient
@@ -343,9 +349,11 @@ class KEEPModel:
             # Columns that are padding in EVERY row change nothing (their softmax weight is exactly 0, positions are
             # absolute, the pooler reads token 0): run the tower at the longest valid length, rounded up to 16.
             # A row with no valid token attends uniformly over all T keys in HF, so such a batch is left alone.
-            valid = msk_d != 0
+            # The length is taken from the caller's mask where it lives: a host mask (the tokenizer's output) costs no device sync.
+            src_mask = text_inputs.get("attention_mask") if hasattr(text_inputs, "get") else text_inputs["attention_mask"]
+            valid = (src_mask if src_mask.device.type == "cpu" else msk_d) != 0
             col = torch.nonzero(valid.any(dim=0)).flatten()
-            info = torch.stack([col[-1] + 1 if col.numel() else torch.zeros((), dtype=torch.int64, device=self._device),
+            info = torch.stack([col[-1] + 1 if col.numel() else torch.zeros((), dtype=torch.int64, device=valid.device),
                                 (~valid.any(dim=1)).any().to(torch.int64)]).tolist()
             L = min(T, max(16, -(-info[0] // 16) * 16))
             if info[1] == 0 and L < T:
@@ -357,9 +365,35 @@ class KEEPModel:
         st = _stream(self._device)
         _lib.check(self._handle, lib.keep_encode_text(self._handle, _ptr(ids_d), _ptr(typ_d), _ptr(msk_d), P, T,
                                                       _ptr(out), st), "encode_text")
-        if self.check_token_ids and lib.keep_token_error(self._handle, st) == 1:
+        if self.check_token_ids == "lazy":
+            flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            _lib.check(self._handle, lib.keep_token_error_async(self._handle, _ptr(flag), st), "token_error_async")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._device))
+            self._pending_token_check = (flag, ev)
+        elif self.check_token_ids and lib.keep_token_error(self._handle, st) == 1:
             raise IndexError("index out of range in self (input_ids / token_type_ids outside the embedding tables)")
-        return out if src_dev == self._device else out.to(src_dev)
+        if src_dev == self._device:
+            return out
+        res = out.to(src_dev)                  # host inputs: the copy back synchronises anyway, so the check is free and immediate
+        self.check_errors(wait=True)
+        return res
+
+    def check_errors(self, wait: bool = True):
+        """Raise the IndexError of an earlier ``encode_text`` call whose token ids were out of range (lazy checking).  Called by
+        every engine entry point with ``wait=False`` (only looks at results that have already arrived)."""
+        pend = self._pending_token_check
+        if pend is None:
+            return
+        flag, ev = pend
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._pending_token_check = None
+        if int(flag.item()) != 0:
+            raise IndexError("index out of range in self (input_ids / token_type_ids of an earlier encode_text call were outside "
+                             "the embedding tables)")
 
     def forward(self, image_inputs, text_inputs):
         """keep_inference.py:65-73."""

@@ -294,8 +294,20 @@ def test_graph_replay_is_bit_identical(small):
     bad = {k: v.clone() for k, v in toks.items()}
     bad["input_ids"][0, 3] = 10 ** 6
     with pytest.raises(IndexError):
-        m.encode_text(bad)
+        m.encode_text(bad)                        # device inputs: reported lazily (no host synchronisation per call) ...
+        m.check_errors()                          # ... at the next engine call or here
     m.encode_text(toks)
+    # lazy reporting: the call itself returns, the NEXT engine call raises; immediate mode raises in the call
+    m.encode_text(bad)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        m.encode_image(x1)
+    m.encode_image(x1)                            # reported once
+    m.check_token_ids = True
+    with pytest.raises(IndexError):
+        m.encode_text(bad)
+    m.check_token_ids = False
+    m.encode_text(bad); m.check_errors()          # never checked
 
 
 def test_every_path_boundary_agrees_with_the_plain_path(small):
