@@ -35,8 +35,11 @@ def main():
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("KEEP_EXAMPLE_FORCE_DIST") == "1"       # the override pushes a 1-GPU run through RCCL as well
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     shape = KEEPShape() if args.depth >= 24 else small_shape(args.depth, max(1, args.depth // 2))
@@ -79,10 +82,10 @@ def main():
     torch.cuda.synchronize()
     t_slide = time.perf_counter() - t0
     if rank == 0:
-        print(f"{args.tiles} tiles on {world} GPU(s): encode {t_enc:.3f}s ({args.tiles / t_enc:.0f} tiles/s incl. tile generation), "
+        print(f"{args.tiles} tiles on {world} GPU(s){' (RCCL process group)' if use_dist else ''}: encode {t_enc:.3f}s ({args.tiles / t_enc:.0f} tiles/s incl. tile generation), "
               f"slide-level steps {t_slide * 1e3:.1f} ms; label={label} tumour_ratio={ratio:.4f} "
               f"seg_map={len(seg)} tiles, fp16 prob map {tuple(prob16.shape)}")
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
