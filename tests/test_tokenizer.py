@@ -1,5 +1,6 @@
-"""Row a8: the tokenizer call.  A synthetic vocabulary (the PubMedBERT one is not available offline) through the same
-third-party library the reference uses, checked against the oracle's restatement of uncased WordPiece."""
+"""Row a8: the tokenizer.  keep_amd's native WordPiece implementation against (1) the oracle's restatement of uncased WordPiece
+and (2) transformers.BertTokenizerFast -- the class the reference's AutoTokenizer returns -- token for token, on a synthetic
+vocabulary (the PubMedBERT one is not available offline)."""
 import os
 
 import pytest
@@ -10,7 +11,8 @@ from oracle import keep_oracle as O
 
 WORDS = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "an", "of", "the", "image", "h", "&", "e", ".", ",", "-",
          "histo", "##path", "##ology", "tumor", "tumour", "normal", "tissue", "clear", "cell", "renal", "carcinoma",
-         "##s", "papillary", "chromo", "##phobe", "lympho", "##cyte", "##cytes", "slide", "showing", "(", ")", "20", "##x"]
+         "##s", "papillary", "chromo", "##phobe", "lympho", "##cyte", "##cytes", "slide", "showing", "(", ")", "20", "##x",
+         "##-", "癌", "細", "胞", "naive", "cafe", "##e", "µ", "m", "µm", "5", "!", "?", "[", "]", "mask", "x", "##y", "##z", "β", "##β"]
 
 
 @pytest.fixture()
@@ -37,6 +39,34 @@ def test_reference_call_layout_and_wordpiece(vocab_dir):
     # [CLS] ... [SEP] [PAD]*; the long text is truncated to 256 with [SEP] last
     assert enc["input_ids"][4, 0] == vocab["[CLS]"] and enc["input_ids"][4, 255] == vocab["[SEP]"] and int(enc["attention_mask"][4].sum()) == 256
     assert enc["input_ids"][3].tolist()[:3] == [vocab["[CLS]"], vocab["[SEP]"], vocab["[PAD]"]]
+
+
+TRICKY = ["An H&E image of Clear Cell Renal Cell Carcinoma.", "a histopathology slide showing lymphocytes (20x)", "", "   ",
+          "papillary tumours, chromophobe; unknownword", "tumor " * 400, "Tumör-tissue", "naïve café CAFÉ", "癌細胞 tumor細胞", "5µm µ m",
+          "a\tb\nc\r\nd\u00a0e\u2003f", "tab\x00null\ufffdrepl\x07bell\u200bzw", "x" * 101 + " " + "x" * 100, "tumor[MASK]cell [SEP] [CLS][PAD]",
+          "!?[]", "ǅ İstanbul ß ſ", "xyz xyzz βββ", "e\u0301 a\u0300 normal"]
+
+
+def test_native_tokenizer_matches_bert_tokenizer_fast(vocab_dir):
+    """Token for token against the tokenizer class the reference gets from AutoTokenizer (uncased BERT: clean-up, CJK isolation,
+    accent stripping, lower-casing, punctuation splitting, greedy WordPiece, 100-character limit, special tokens in the text)."""
+    transformers = pytest.importorskip("transformers")
+    hf = transformers.BertTokenizerFast.from_pretrained(vocab_dir, local_files_only=True, do_lower_case=True)
+    assert hf.vocab_size == len(WORDS)
+    nat = load_tokenizer(vocab_dir)
+    assert type(nat).__name__ == "WordPieceTokenizer"
+    a = hf(TRICKY, max_length=256, padding="max_length", truncation=True, return_tensors="pt")
+    b = nat(TRICKY, max_length=256, padding="max_length", truncation=True, return_tensors="pt")
+    for i, t in enumerate(TRICKY):
+        n = int(a["attention_mask"][i].sum())
+        assert b["input_ids"][i].tolist() == a["input_ids"][i].tolist(), (t, hf.convert_ids_to_tokens(a["input_ids"][i][:n].tolist()))
+        assert b["attention_mask"][i].tolist() == a["attention_mask"][i].tolist() and int(b["token_type_ids"][i].sum()) == 0
+    # the other call shapes of the HF surface that the examples use
+    assert nat("a tumor")["input_ids"][0] == hf("a tumor")["input_ids"]
+    lo = nat(TRICKY[:3], padding=True, return_tensors="pt")
+    assert lo["input_ids"].shape == hf(TRICKY[:3], padding=True, return_tensors="pt")["input_ids"].shape
+    assert lo.to("cpu").input_ids.dtype == torch.int64
+    assert type(load_tokenizer(vocab_dir, backend="hf")).__name__.startswith("Bert")
 
 
 def test_missing_vocabulary_is_an_error(tmp_path):
