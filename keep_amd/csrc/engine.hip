@@ -1027,6 +1027,7 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
         HIPCHK(h, hipMemcpyAsync(out, st_out, ob, hipMemcpyDeviceToDevice, s));
         return KEEP_OK;
     }
+    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : (pix_dtype == KEEP_PIX_U8_HWC ? 1 : 2);    // bytes per value; 3*224*224 values per tile in every layout
     // lanes: split the batch over n_streams concurrent sub-batches once there is enough work for each
     int lanes = h->n_streams;
     while (lanes > 1 && B < (int64_t)lanes * h->lane_min_tiles) --lanes;
@@ -1048,7 +1049,6 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
         HIPCHK(h, hipEventRecord(h->ev_fork, s));
         for (int l = 0; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->aux[l], h->ev_fork, 0));
     }
-    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : (pix_dtype == KEEP_PIX_U8_HWC ? 1 : 2);    // bytes per value; 3*224*224 values per tile in every layout
     for (int64_t b0 = 0; b0 < B; b0 += per * lanes) {
         VitLane L[4];
         int nl = 0;
@@ -1228,17 +1228,18 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
         // top-2 score in the accumulator registers and sums it over the tile's rows; no logit reaches HBM.
         const int64_t KCp = (KC + 255) / 256 * 256, nslots = (N + 255) / 256 * 2, kpad = KCp / C;
         const bool comp = h->fused_screening == 1;                      // 1: fp16 + MX-fp4 corrections; 2: three fp16 passes
-        Carver cv(nullptr);
-        const size_t o_ahi = cv.off; cv.take<f16>(blk_elems(N, D));
-        const size_t o_alo = cv.off; cv.take<f16>(comp ? 0 : blk_elems(N, D));
-        const size_t o_aq = cv.off;  cv.take<unsigned char>(keepk::q4_data_bytes(N, D));
-        const size_t o_asc = cv.off; cv.take<unsigned char>(keepk::q4_scale_bytes(N, D));
-        const size_t o_whi = cv.off; cv.take<f16>(blk_elems(KCp, D));
-        const size_t o_wlo = cv.off; cv.take<f16>(blk_elems(KCp, D));
-        const size_t o_wq = cv.off;  cv.take<unsigned char>(keepk::q4_data_bytes(KCp, D));
-        const size_t o_wsc = cv.off; cv.take<unsigned char>(keepk::q4_scale_bytes(KCp, D));
-        const size_t o_part = cv.off; cv.take<float>((size_t)nslots * kpad);
-        int rc = ensure_arena(h, cv.off);
+        size_t total = 0;
+        auto reserve = [&](size_t bytes) { const size_t at = total; total += align_up(bytes); return at; };     // offsets first: the arena may move
+        const size_t o_ahi = reserve(blk_elems(N, D) * sizeof(f16));
+        const size_t o_alo = reserve(comp ? 0 : blk_elems(N, D) * sizeof(f16));
+        const size_t o_aq = reserve(keepk::q4_data_bytes(N, D));
+        const size_t o_asc = reserve(keepk::q4_scale_bytes(N, D));
+        const size_t o_whi = reserve(blk_elems(KCp, D) * sizeof(f16));
+        const size_t o_wlo = reserve(blk_elems(KCp, D) * sizeof(f16));
+        const size_t o_wq = reserve(keepk::q4_data_bytes(KCp, D));
+        const size_t o_wsc = reserve(keepk::q4_scale_bytes(KCp, D));
+        const size_t o_part = reserve((size_t)nslots * kpad * sizeof(float));
+        int rc = ensure_arena(h, total);
         if (rc) return rc;
         char* a = h->arena;
         launch_quant_blockify(feats, (f16*)(a + o_ahi), comp ? nullptr : (f16*)(a + o_alo), (unsigned char*)(a + o_aq), (unsigned char*)(a + o_asc), (int)N, (int)D, s);
