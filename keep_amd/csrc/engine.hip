@@ -392,7 +392,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     const int mlp = h->vit_mlp_mode(i, cls_only ? 0 : Bc);             // fc1 / fc2: 0 plain, 1 split, 2 compensated (MX-fp4 corrections)
     const bool mlp_lo = mlp == 1, mlp_q = mlp == 2;
 #ifdef KEEP_DIAGNOSTICS
-    const bool skip_ln = h->dbg_skip_ln && h->dbg_calls > 3;
+    const bool skip_ln = h->dbg_skip_ln == 1 && h->dbg_calls > 3;
 #else
     const bool skip_ln = false;
 #endif
@@ -420,6 +420,9 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
         a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
         a.q_rows = cls_only ? 1 : 0;
+#ifdef KEEP_DIAGNOSTICS
+        if (!(h->dbg_skip_ln == 2 && h->dbg_calls > 3))      // dbg_skip_ln = 2: skip the attention launches instead (bounds what a faster attention could gain)
+#endif
         if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "attention launch failed");
     }
     mark(2);
