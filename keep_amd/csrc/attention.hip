@@ -29,12 +29,19 @@ __host__ __device__ constexpr int att_kp2(int NT) { return ((NT + 1) / 2) * 32; 
 // banks -- conflict free (KP2 + 8 measured 35 % of the kernel's LDS cycles as bank conflicts).
 __host__ __device__ constexpr int att_vs(int NT) { return att_kp2(NT) + 4; }
 __host__ __device__ constexpr size_t att_lds_bytes(int NT, bool split) {
-    size_t one = (size_t)NT * 16 * HD * 2 + (size_t)HD * att_vs(NT) * 2;
+    size_t one = (size_t)NT * 16 * HD * 2 + (size_t)att_kp2(NT) * HD * 2;       // K image + V image, both row-major [key][64]
     return one * (split ? 2 : 1) + (size_t)NT * 16 * 4;
 }
 
 __device__ __forceinline__ unsigned sel4(const uint4& x, int i) {
     return i == 0 ? x.x : (i == 1 ? x.y : (i == 2 ? x.z : x.w));
+}
+
+typedef __fp16 att_h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane i receives as element e the element (i % 4) of source lane (4 e + i / 4)
+__device__ __forceinline__ f16x4 tr_read4(const f16* p) {
+    const att_h16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((att_h16x4 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(f16x4, v);
 }
 
 typedef const __attribute__((address_space(1))) void* att_gptr_t;
@@ -67,38 +74,24 @@ __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok,
                                              (att_lptr_t)(sK + (it * ATT_THREADS + wave * 64) * 8), 16, 0, 0);
         }
     }
-    // V^T: work item = (key pair kp, 16-byte chunk c).  A wavefront takes 64 consecutive key pairs of ONE
-    // chunk, so its 8 transposed stores (one per feature of the chunk) each write 64 consecutive dwords of
-    // one V^T row: conflict-free without any data-dependent register selection (the first version rotated
-    // the element order per lane with a select chain, which the compiler turned into ~200 exec-mask
-    // branches -- the kernel was VALU-issue bound on its own staging code).
-    constexpr int NPAIR_PAD = (NPAIR + 63) / 64 * 64;
-    constexpr int V_IT2 = (NPAIR_PAD * 8 + ATT_THREADS - 1) / ATT_THREADS;
-    uint4 va[V_IT2], vb[V_IT2];
+    // V: row-major as well, by LDS-DMA.  The P.V MFMA wants V^T fragments (4 consecutive keys of ONE feature per lane); they are
+    // produced at read time by ds_read_b64_tr_b16 (a 4x4 transpose between the lanes of a quad group and their element slots,
+    // semantics measured in tools/ubench/tr_probe.hip), so no transposed copy of V is built -- the register transposition that used to
+    // be here (all V loads, select-free repacking, 2-byte-pair stores) was about a quarter of the kernel.  32-byte granules of a row
+    // are XOR-swizzled with (row >> 1) & 3 (on the SOURCE address, the LDS image stays lane-linear): the 8 rows x 32 B a half-wave
+    // reads then fall on 64 distinct banks.
+    constexpr int VROWS = att_kp2(NT);
+    constexpr int V_ITEMS2 = VROWS * 8;
+    constexpr int V_IT3 = (V_ITEMS2 + ATT_THREADS - 1) / ATT_THREADS;
 #pragma unroll
-    for (int it = 0; it < V_IT2; ++it) {
-        int idx = tid + it * ATT_THREADS;
-        idx = idx < NPAIR_PAD * 8 ? idx : NPAIR_PAD * 8 - 1;
-        const int c = idx / NPAIR_PAD;
-        int kp = idx % NPAIR_PAD;
-        kp = kp < NPAIR ? kp : NPAIR - 1;
-        const int r0 = 2 * kp < ntok ? 2 * kp : ntok - 1, r1 = 2 * kp + 1 < ntok ? 2 * kp + 1 : ntok - 1;
-        va[it] = *reinterpret_cast<const uint4*>(base + (int64_t)r0 * D3 + voff + c * 8);
-        vb[it] = *reinterpret_cast<const uint4*>(base + (int64_t)r1 * D3 + voff + c * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < V_IT2; ++it) {
-        const int idx = tid + it * ATT_THREADS;
-        const int c = idx / NPAIR_PAD, kp = idx % NPAIR_PAD;
-        if (kp < NPAIR && idx < NPAIR_PAD * 8) {
-            const unsigned wa[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
-            const unsigned wb[4] = {vb[it].x, vb[it].y, vb[it].z, vb[it].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int sh = (e & 1) * 16;
-                const unsigned packed = ((wa[e >> 1] >> sh) & 0xffffu) | (((wb[e >> 1] >> sh) & 0xffffu) << 16);
-                *reinterpret_cast<unsigned*>(sVt + (c * 8 + e) * VS + 2 * kp) = packed;
-            }
+    for (int it = 0; it < V_IT3; ++it) {
+        const int L = tid + it * ATT_THREADS;              // V_ITEMS2 is a multiple of 128: wave-uniform predicate
+        if (L < V_ITEMS2) {
+            const int row = L >> 3, p = L & 7;
+            const int c = ((((p >> 1) ^ ((row >> 1) & 3)) << 1) | (p & 1));
+            const int rc = row < ntok ? row : ntok - 1;
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(base + (int64_t)rc * D3 + voff + c * 8),
+                                             (att_lptr_t)(sVt + (it * ATT_THREADS + wave * 64) * 8), 16, 0, 0);
         }
     }
 }
@@ -114,8 +107,8 @@ void attention_kernel(AttnParams p) {
     constexpr int NU = (NT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f16* sK = reinterpret_cast<f16*>(smem);
-    f16* sVt = sK + NKP * HD;
-    float* sBias = reinterpret_cast<float*>(sVt + HD * VS);
+    f16* sVt = sK + NKP * HD;                              // V, row-major [att_kp2(NT)][64] (see stage_kv)
+    float* sBias = reinterpret_cast<float*>(sVt + att_kp2(NT) * HD);
     f16* sKl = reinterpret_cast<f16*>(sBias + NKP);
     f16* sVtl = sKl + NKP * HD;
 
@@ -228,15 +221,19 @@ void attention_kernel(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         f16x4 va[2][4][2], vb[2][4][2];      // [slot][dt][half]  hi / lo planes
+        // lane (qi, g) points at V[32u + 16 half + 4g + qi/4][16 dt + 4 (qi%4) ..+3]; the transpose read hands it
+        // V[32u + 16 half + 4g + 0..3][16 dt + qi]: keys 4g..4g+3 of feature qi, the slots P occupies in the B operand
         auto load_v = [&](int u, int slot) {
+            const int vrow = 32 * u + 4 * g + (qi >> 2);
+            const int vsw = (2 * g + (qi >> 3)) & 3;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int voff = (dt * 16 + qi) * VS + 32 * u + g * 4;
-                va[slot][dt][0] = *reinterpret_cast<const f16x4*>(sVt + voff);
-                va[slot][dt][1] = *reinterpret_cast<const f16x4*>(sVt + voff + 16);
+                const int voff = vrow * HD + ((dt ^ vsw) << 4) + ((qi & 3) << 2);
+                va[slot][dt][0] = tr_read4(sVt + voff);
+                va[slot][dt][1] = tr_read4(sVt + voff + 16 * HD);
                 if (SPLIT) {
-                    vb[slot][dt][0] = *reinterpret_cast<const f16x4*>(sVtl + voff);
-                    vb[slot][dt][1] = *reinterpret_cast<const f16x4*>(sVtl + voff + 16);
+                    vb[slot][dt][0] = tr_read4(sVtl + voff);
+                    vb[slot][dt][1] = tr_read4(sVtl + voff + 16 * HD);
                 }
             }
         };
