@@ -372,6 +372,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     if constexpr (COMP) {
         static_assert(BN == 256 && WM == 2 && WN == 4, "phase 2 is written for the 2 x 4 wave grid of the 256 x 256 tile");
         constexpr int G2 = 5;                                   // DMA instructions per wave per chunk
+        if (p.dbg) t_first = __builtin_readcyclecounter();       // diagnostics: in a compensated launch stamp 1 marks the end of the fp16 phase
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // every wave is done with the phase-1 ring (its DMA queue is already drained)
         const int NC = p.K >> 6;
