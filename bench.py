@@ -212,7 +212,7 @@ def main():
     log(f"start: world={world} cpus={usable_cpus()} (os.cpu_count={os.cpu_count()})")
     torch.set_num_threads(min(usable_cpus(), 16))
     shape = KEEPShape()
-    want_configs = rank == 0 and not args.no_configs
+    want_configs = rank == 0 and world == 1 and not args.no_configs      # the config-3 parity / c3 / c5 legs belong to the 1-GPU line; scaling runs stay lean
     sd = synth_state_dict(shape, seed=0, text=want_configs)          # identical image-tower weights on every rank; rank 0 adds the text tower for config 3
     model = KEEPModel(shape, precision=args.precision, towers=("image", "text") if want_configs else ("image",))
     model.precision_name = args.precision
