@@ -204,7 +204,7 @@ int keep_profile_reset(keep_handle* h);
  *   epi 0: out[M,N] = acc+bias            1: gelu(acc+bias)
  *       2: out = resid + ls*(acc+bias)    4: out = resid + acc + bias      (resid, ls fp32)
  *   split 1 runs the 3-pass hi/lo product, split 2 the compensated product (fp16 pass + MX-fp4 correction terms;
- *   N % 256 == 0, K % 64 == 0, epi 0..2).  Outputs of epi 0/1 are the fp16-rounded values (hi, or hi+lo when
+ *   N % 256 == 0, K % 128 == 0, K >= 256, epi 0..2).  Outputs of epi 0/1 are the fp16-rounded values (hi, or hi+lo when
  *   split != 0) converted back to fp32. */
 int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls,
                    const float* resid, int64_t M, int64_t N, int64_t K, int epi, int split, float* out,

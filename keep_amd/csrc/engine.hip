@@ -42,7 +42,7 @@ struct WTensor {
     f16* hi = nullptr;        // GEMM weights: fp16 planes
     f16* lo = nullptr;
     f16* frag = nullptr;      // hi plane in MFMA-fragment order (common.h frag_off): W-direct path of the 256x256 GEMM
-    unsigned char* q = nullptr;   // MX-fp4 side planes of (hi, lo) and their scales (quant4.h); K % 64 == 0 weights only
+    unsigned char* q = nullptr;   // MX-fp4 side planes of (hi, lo) and their scales (quant4.h); K % 128 == 0 weights only
     unsigned char* sc = nullptr;
 };
 
@@ -147,7 +147,7 @@ struct keep_handle {
     bool txt_split(int l, int T) const { return precision == KEEP_PREC_STRICT || l < strict_blocks || (precision == KEEP_PREC_COMP && T <= 256); }
     bool txt_must_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
     bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
-    bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 64 == 0)
+    bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 128 == 0)
     bool any_comp() const { return precision == KEEP_PREC_COMP && comp_mlp_blocks > 0 && vit_has_q; }
 
     bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && tag == prof_tag); }
@@ -606,7 +606,7 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
         HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
         // the MLP weights of the image tower also get the MX-fp4 side planes of the compensated product (quant4.h)
-        if (key.find(".mlp.fc") != std::string::npos && starts_with(key, "visual.") && k % 64 == 0) {
+        if (key.find(".mlp.fc") != std::string::npos && starts_with(key, "visual.") && k % 128 == 0 && k >= 256) {
             HIPCHK(h, hipMalloc(&t.q, keepk::q4_data_bytes(n, k)));
             HIPCHK(h, hipMalloc(&t.sc, keepk::q4_scale_bytes(n, k)));
             launch_quant_blockify(dev, t.hi, t.lo, t.q, t.sc, (int)n, (int)k, nullptr);
@@ -1226,7 +1226,7 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
     hipStream_t s = (hipStream_t)stream;
     Scope sc(h, T_SIM, s);
     const int64_t KC = K * C;
-    if ((C == 2 || C == 4) && D % 64 == 0 && h->fused_screening) {
+    if ((C == 2 || C == 4) && D % 128 == 0 && D >= 256 && h->fused_screening) {
         // Fused path: ONE compensated GEMM [N,D] x [D,K*C] whose epilogue takes the per-(tile, classifier)
         // top-2 score in the accumulator registers and sums it over the tile's rows; no logit reaches HBM.
         const int64_t KCp = (KC + 255) / 256 * 256, nslots = (N + 255) / 256 * 2, kpad = KCp / C;
@@ -1398,7 +1398,7 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     const bool comp = split == 2;
     unsigned char *a_q = nullptr, *a_sc = nullptr, *w_q = nullptr, *w_sc = nullptr;
     if (comp) {
-        if (rowmajor || N % 256 || K % 64 || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%64==0 and epilogue 0/1/2");
+        if (rowmajor || N % 256 || K % 128 || K < 256 || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%128==0, K>=256 and epilogue 0/1/2");
         a_q = t.get<unsigned char>(keepk::q4_data_bytes(M, K)); a_sc = t.get<unsigned char>(keepk::q4_scale_bytes(M, K));
         w_q = t.get<unsigned char>(keepk::q4_data_bytes(N, K)); w_sc = t.get<unsigned char>(keepk::q4_scale_bytes(N, K));
         if (!a_q || !a_sc || !w_q || !w_sc) return h->fail(KEEP_ENOMEM, "temp alloc");

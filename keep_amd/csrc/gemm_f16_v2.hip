@@ -53,8 +53,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int v2_waves_per_simd(int BN, int WM, int WN) { return (V2_BM / WM / 32) * (BN / WN / 32) * 16 > 128 ? 1 : 2; }
 
 typedef int v8i __attribute__((ext_vector_type(8)));
-constexpr int V2_ST2 = 34816;        // phase-2 LDS stage: 16 KiB A planes + 16 KiB W planes + 1 KiB + 1 KiB of scales (one K = 64 chunk)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// phase-2 LDS ring (one K = 64 chunk per stage): the 16 KiB of A planes + 16 KiB of W planes of stage b sit exactly on phase-1 stage b
+// (32 KiB each), the 1 KiB + 1 KiB of block scales behind the phase-1 ring -- so the first chunks can be staged into phase-1 stages as
+// those retire, under the last fp16 steps.
+constexpr int V2_ST2 = 32768;
+constexpr int V2_SC2 = 2048;
 constexpr int V2_NST2 = 4;
+constexpr int V2_SC2_BASE = V2_NST2 * V2_ST2;
+constexpr int V2_G2 = 5;             // phase-2 DMA instructions per wave per chunk
 
 // WD ("W direct", -DKEEP_EXPERIMENTS builds only): the W fragments come straight from global memory into registers
 // (fragment-ordered plane, common.h frag_off) and only A goes through the LDS ring: half of the LDS-DMA writes and a third of the
@@ -214,6 +221,30 @@ void gemm_f16_v2_kernel(GemmParams p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
     };
     auto mfma_group = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) { mfma_head(fw, fa); mfma_tail(fw, fa); };
+    // phase-2 (MX-fp4 correction terms, COMP only) operand stream; defined here because its first chunks are issued from the fp16 loop
+    const unsigned char* aq = nullptr; const unsigned char* wq = nullptr; const unsigned char* sq = nullptr;
+    if constexpr (COMP) {
+        aq = p.a_q + (int64_t)(m0 >> 8) * KT * 8192;
+        wq = p.w_q + (int64_t)(n0 >> 8) * KT * 8192;
+        sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512) + (wave & 3) * 256;     // wave-uniform; lanes add 4 * lane
+    }
+    auto stage2 = [&](int c, int buf) {
+        unsigned char* sb = smem_raw + buf * V2_ST2;
+        // scalar base + one 32-bit lane offset per instruction.  The empty asm keeps the offsets from being folded into 64-bit lane
+        // addresses that would be hoisted out of the fp16 loop and held in registers (spilled, in fact) across it.
+        unsigned v16 = tid * 16, v4 = lane * 4;
+        asm volatile("" : "+v"(v16), "+v"(v4));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(aq + ((int64_t)c * 16384 + r * 8192) + v16), (lptr_t)(sb + (r * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wq + ((int64_t)c * 16384 + r * 8192) + v16), (lptr_t)(sb + 16384 + (r * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(sq + (int64_t)c * 1024 + v4), (lptr_t)(smem_raw + V2_SC2_BASE + buf * V2_SC2 + (wave >> 2) * 1024 + (wave & 3) * 256), 4, 0, 0);
+    };
+    // PRE: chunks 0..2 of phase 2 go out from the last fp16 steps, each into the phase-1 stage that step has just retired (chunk c lands in
+    // stage c: the launcher admits compensated products only with a step count that is a multiple of the ring depth, K % 128 == 0, and
+    // K >= 256) -- the fp4 phase then starts with its ring already full.
+    constexpr bool PRE = COMP && !WD && NSTAGE == V2_NST2;
 #define KEEP_PIN() __builtin_amdgcn_sched_barrier(0)
 
   if constexpr (WD) {
@@ -333,28 +364,42 @@ void gemm_f16_v2_kernel(GemmParams p) {
         mfma_head(fw1, fa1);
         KEEP_PIN();
         if (s + NSTAGE < steps) stage(s + NSTAGE, s % NSTAGE);
+        else if constexpr (PRE) stage2(0, 0);               // s == steps - NSTAGE: stage 0 is free
         read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
         KEEP_PIN();
         mfma_tail(fw1, fa1);
     }
-    // drain: fewer tiles in flight, wait for everything that is left
-    for (; s < steps - 1; ++s) {
-        mfma_head(fw0, fa0);
-        KEEP_PIN();
-        read_frags(s % NSTAGE, 1, fw1, fa1);
-        KEEP_PIN();
-        mfma_tail(fw0, fa0);
-        KEEP_PIN();
-        wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        KEEP_PIN();
-        mfma_head(fw1, fa1);
-        KEEP_PIN();
-        read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
-        KEEP_PIN();
-        mfma_tail(fw1, fa1);
+    // drain: fewer tiles in flight
+#define KEEP_DRAIN_STEP(WAIT, AFTER)                                                                                               \
+    {                                                                                                                              \
+        mfma_head(fw0, fa0);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        read_frags(s % NSTAGE, 1, fw1, fa1);                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        mfma_tail(fw0, fa0);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        wait_vmcnt<WAIT>();                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                              \
+        KEEP_PIN();                                                                                                                \
+        mfma_head(fw1, fa1);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        AFTER;                                                                                                                     \
+        read_frags((s + 1) % NSTAGE, 0, fw0, fa0);                                                                                 \
+        KEEP_PIN();                                                                                                                \
+        mfma_tail(fw1, fa1);                                                                                                       \
     }
+    if constexpr (PRE) {
+        // in-order retirement: step steps-3 needs tile steps-2, younger are tile steps-1 (G) and chunk 0; step steps-2 needs tile steps-1,
+        // younger are chunks 0 and 1
+        KEEP_DRAIN_STEP(G + V2_G2, stage2(1, 1))
+        ++s;
+        KEEP_DRAIN_STEP(2 * V2_G2, stage2(2, 2))
+        ++s;
+    } else {
+        for (; s < steps - 1; ++s) KEEP_DRAIN_STEP(0, (void)0)          // wait for everything that is left
+    }
+#undef KEEP_DRAIN_STEP
     mfma_head(fw0, fa0);
     KEEP_PIN();
     read_frags(s % NSTAGE, 1, fw1, fa1);
@@ -371,30 +416,25 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // one raw barrier per chunk.
     if constexpr (COMP) {
         static_assert(BN == 256 && WM == 2 && WN == 4, "phase 2 is written for the 2 x 4 wave grid of the 256 x 256 tile");
-        constexpr int G2 = 5;                                   // DMA instructions per wave per chunk
+        constexpr int G2 = V2_G2;
         if (p.dbg) t_first = __builtin_readcyclecounter();       // diagnostics: in a compensated launch stamp 1 marks the end of the fp16 phase
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // every wave is done with the phase-1 ring (its DMA queue is already drained)
         const int NC = p.K >> 6;
-        const unsigned char* aq = p.a_q + (int64_t)(m0 >> 8) * KT * 8192;
-        const unsigned char* wq = p.w_q + (int64_t)(n0 >> 8) * KT * 8192;
-        const unsigned char* sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512) + (wave & 3) * 256 + lane * 4;
-        auto stage2 = [&](int c, int buf) {
-            unsigned char* sb = smem_raw + buf * V2_ST2;
+        if constexpr (PRE) {
+            // chunks 0..2 are in flight since the last fp16 steps: one barrier both retires the phase-1 ring and publishes chunk 0
+            wait_vmcnt<G2 * (V2_NST2 - 2)>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // every wave is done with the phase-1 ring (its DMA queue is already drained)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(aq + (int64_t)c * 16384 + (r * 512 + tid) * 16), (lptr_t)(sb + (r * 512 + wave * 64) * 16), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(wq + (int64_t)c * 16384 + (r * 512 + tid) * 16), (lptr_t)(sb + 16384 + (r * 512 + wave * 64) * 16), 16, 0, 0);
-            }
-            __builtin_amdgcn_global_load_lds((gptr_t)(sq + (int64_t)c * 1024), (lptr_t)(sb + 32768 + (wave >> 2) * 1024 + (wave & 3) * 256), 4, 0, 0);
-        };
-#pragma unroll
-        for (int t = 0; t < V2_NST2 - 1; ++t)
-            if (t < NC) stage2(t, t);
-        if (NC >= V2_NST2 - 1) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+            for (int t = 0; t < V2_NST2 - 1; ++t)
+                if (t < NC) stage2(t, t);
+            if (NC >= V2_NST2 - 1) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         const int a_row = (wm * 128 + frow) * 16, w_row = (wn * 64 + frow) * 16;
-        const int asc_off = 32768 + fhi * 512 + (wm * 32 + frow) * 4, wsc_off = 32768 + 1024 + fhi * 512 + ((wn >> 1) * 32 + frow) * 4;
+        const int asc_off = fhi * 512 + (wm * 32 + frow) * 4, wsc_off = 1024 + fhi * 512 + ((wn >> 1) * 32 + frow) * 4;
         const int wsh = (wn & 1) * 16;
         // One step per chunk: fetch the 12 fragments + 4 scale dwords, issue the DMA of chunk c+3, 16 MFMAs, counted wait, barrier.
         // The phase is bound by the LDS-DMA stream, like phase 1 (34 KiB per chunk against 64 KiB per K = 64 there, and it takes
@@ -407,21 +447,24 @@ void gemm_f16_v2_kernel(GemmParams p) {
             acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
         for (int c = 0; c < NC; ++c) {
             const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
+            const unsigned char* ss = smem_raw + V2_SC2_BASE + (c & (V2_NST2 - 1)) * V2_SC2;
             const unsigned char* sa = sb + fhi * 8192;                  // this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31
             const unsigned char* sw = sb + 16384 + fhi * 8192;
-            uint4 ah[4], al[4], wh[2], wl[2];
+            // native vector type, not HIP's uint4 struct: a struct load carries no alias info, and hipcc then puts an s_waitcnt vmcnt(0)
+            // ("may read what an LDS-DMA in flight writes") in front of it -- which drains the ring on every chunk
+            u32x4 ah[4], al[4], wh[2], wl[2];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                ah[jj] = *reinterpret_cast<const uint4*>(sa + a_row + jj * 512);
-                al[jj] = *reinterpret_cast<const uint4*>(sa + 4096 + a_row + jj * 512);
+                ah[jj] = *reinterpret_cast<const u32x4*>(sa + a_row + jj * 512);
+                al[jj] = *reinterpret_cast<const u32x4*>(sa + 4096 + a_row + jj * 512);
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
-                wh[ii] = *reinterpret_cast<const uint4*>(sw + w_row + ii * 512);
-                wl[ii] = *reinterpret_cast<const uint4*>(sw + 4096 + w_row + ii * 512);
+                wh[ii] = *reinterpret_cast<const u32x4*>(sw + w_row + ii * 512);
+                wl[ii] = *reinterpret_cast<const u32x4*>(sw + 4096 + w_row + ii * 512);
             }
-            const int sah = *reinterpret_cast<const int*>(sb + asc_off), sal = *reinterpret_cast<const int*>(sb + asc_off + 256);
-            const int swh = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off) >> wsh), swl = (int)(*reinterpret_cast<const unsigned*>(sb + wsc_off + 256) >> wsh);
+            const int sah = *reinterpret_cast<const int*>(ss + asc_off), sal = *reinterpret_cast<const int*>(ss + asc_off + 256);
+            const int swh = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off) >> wsh), swl = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off + 256) >> wsh);
             if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));     // the stage chunk c-1 was read from
             KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)
             KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)
@@ -618,7 +661,8 @@ bool v2_opt_in_lds(K kernel, size_t bytes) {
 template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP, bool WD = false>
 int launch_v2_one(const GemmParams& p, hipStream_t s) {
     constexpr size_t ring = (size_t)NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
-    constexpr size_t lds_bytes = COMP && (size_t)V2_NST2 * V2_ST2 > ring ? (size_t)V2_NST2 * V2_ST2 : ring;
+    constexpr size_t ring2 = (size_t)V2_NST2 * (V2_ST2 + V2_SC2);
+    constexpr size_t lds_bytes = COMP && ring2 > ring ? ring2 : ring;
     auto kernel = &gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI, COMP, WD>;
     if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
     const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM) * (EPI == EPI_PARTIAL ? p.ksplit : 1);
@@ -654,7 +698,7 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
                     (variant == 256 || p.comp);
 #endif
     if (p.comp) {
-        if (p.N % 256 || p.K % 64 || p.nseg != 1 || !p.a_q || !p.a_sc || !p.w_q || !p.w_sc) return 1;
+        if (p.N % 256 || p.K % 128 || p.K < 256 || p.nseg != 1 || !p.a_q || !p.a_sc || !p.w_q || !p.w_sc) return 1;
 #ifdef KEEP_EXPERIMENTS
         if (wd && epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, true, true>(p, s);
         if (wd && epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, true, true>(p, s);

@@ -97,7 +97,7 @@ def _rel_rms(out, ref):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1000, 1024, 1024, EPI_F16), (394, 4096, 1024, EPI_GELU_F16), (2048, 1024, 4096, EPI_RESID_LS),
-                                       (257, 256, 64, EPI_F16), (300, 768, 3072, EPI_RESID_LS)])
+                                       (257, 256, 256, EPI_F16), (513, 512, 384, EPI_F16), (300, 768, 3072, EPI_RESID_LS)])
 def test_compensated_linear_recovers_the_fp16_rounding(ops, M, N, K, epi):
     """split=2: A_hi W_hi on the fp16 pipe + Q4(A_hi) Q4(W_lo) + Q4(A_lo) Q4(W_hi) on the MX-fp4 pipe.  The correction terms
     only need 2-3 bits: the result must sit >= 4x closer to the fp64 product than the plain fp16-operand product does
@@ -124,6 +124,14 @@ def test_compensated_linear_recovers_the_fp16_rounding(ops, M, N, K, epi):
     blk = lambda e: e[:Mb, :Nb].reshape(Mb // 32, 32, Nb // 32, 32).pow(2).mean(dim=(1, 3)).sqrt()
     assert (blk(e_comp) < 0.5 * blk(e_fp16).clamp_min(1e-12)).all()
     assert (e_comp[Mb:] .max() if Mb < M else torch.tensor(0.)) < 4 * e_fp16.max()
+
+
+@pytest.mark.parametrize("K", [64, 192, 320])
+def test_compensated_linear_rejects_k_that_does_not_fill_the_ring(ops, K):
+    """The fp4 phase's first chunks are staged into the fp16 ring's stages as they retire: K must be a multiple of 4 K steps (128)
+    and at least 256.  Anything else is refused, not silently computed another way."""
+    with pytest.raises(ValueError, match="K%128"):
+        ops.linear(rand(256, K, seed=1), rand(256, K, seed=2), torch.zeros(256), EPI_F16, 2)
 
 
 def test_compensated_linear_is_not_transposed(ops):
