@@ -98,8 +98,15 @@ __device__ __forceinline__ void stage_kv(const f16* __restrict__ base, int ntok,
 
 // NW wavefronts per workgroup: 4 (two workgroups per CU by LDS) or 8 (the 13 query tiles of a ViT head are
 // spread over twice the waves: 16 waves per CU hide the LDS / exp latencies better).
+// Waves per SIMD the register allocation is planned for.  Two 8-wave workgroups per CU (what the LDS allows) are 4 waves per SIMD = 128
+// registers.  Asking for that bound outright made the NT = 13 kernel SPILL (17 dwords; reloads with s_waitcnt vmcnt(0) in front of every
+// output store), while the unconstrained allocation of the same code lands at 126 registers and gets the same occupancy -- so NT = 13 is
+// left unconstrained; NT = 16 needs the bound (152 registers without it, 118 and no scratch with it).  Checked in the ISA metadata
+// (tests/test_build_artifacts.py: no private segment in any attention / GEMM kernel of the product library).
+__host__ __device__ constexpr int att_min_waves(int NT, int NW) { return NW >= 7 && NT != 13 ? 4 : 2; }
+
 template <int NT, bool SPLIT, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 7 ? 4 : 2)
+__global__ __launch_bounds__(NW * 64, att_min_waves(NT, NW))
 void attention_kernel(AttnParams p) {
     constexpr int ATT_THREADS = NW * 64;
     constexpr int NKP = NT * 16;
@@ -142,16 +149,22 @@ void attention_kernel(AttnParams p) {
     const float sc2 = p.scale * 1.4426950408889634f;
     // Q fragments of the next query tile are fetched while the current one is computed
     f16x8 qn[2], qln[2];
+    // Addresses are a wave-uniform base plus ONE 32-bit lane offset (the launcher refuses buffers of 2^31 elements or more): 64-bit lane
+    // addresses for the Q loads and the output stores were loop invariants the compiler hoisted, ran out of registers on (128 per wave at
+    // this occupancy) and spilled -- every output store of every query tile then sat behind a scratch reload and an s_waitcnt vmcnt(0).
     auto load_q = [&](int qt) {
         int q = qt * 16 + qi;
         q = q < ntok ? q : ntok - 1;
+        const unsigned qo = (unsigned)q * (unsigned)D3 + (unsigned)(h * HD + g * 8);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qn[ks] = *reinterpret_cast<const f16x8*>(base_hi + (int64_t)q * D3 + h * HD + ks * 32 + g * 8);
-            if (SPLIT) qln[ks] = *reinterpret_cast<const f16x8*>(base_lo + (int64_t)q * D3 + h * HD + ks * 32 + g * 8);
+            qn[ks] = *reinterpret_cast<const f16x8*>(base_hi + (qo + ks * 32));
+            if (SPLIT) qln[ks] = *reinterpret_cast<const f16x8*>(base_lo + (qo + ks * 32));
         }
     };
     if (wave < nqt) load_q(wave);
+    asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));          // same as at the bottom of the loop: no pending Q load reaches the loop header on any path
+    if (SPLIT) asm volatile("" : "+v"(qln[0]), "+v"(qln[1]));
     for (int qt = wave; qt < nqt; qt += NW) {
         const int q = qt * 16 + qi;
         f16x8 qf[2], ql[2];
@@ -203,15 +216,34 @@ void attention_kernel(AttnParams p) {
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // exp and the fp16 conversion in one pass, two key tiles (one 32-key MFMA operand) at a time: the fp32 scores die as the packed
+        // probabilities are born, so the P.V loop below holds 26 registers of P instead of 52 (the kernel has 128 at this occupancy)
         float sum = 0.f;
+        f16x8 ph[NU], pl[SPLIT ? NU : 1];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int u = 0; u < NU; ++u) {
+            float a0[4], a1[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-                s[kt][r] = e;
-                sum += e;
+                a0[r] = __builtin_amdgcn_exp2f(s[2 * u][r] - mx);
+                a1[r] = (2 * u + 1 < NT) ? __builtin_amdgcn_exp2f(s[(2 * u + 1 < NT) ? 2 * u + 1 : 0][r] - mx) : 0.f;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += a0[r];          // summation order: key tile by key tile, as the scores are laid out
+            if (2 * u + 1 < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += a1[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // probabilities lie in [0, 1]: no saturation needed (the clamp of split_f16 was 2 of the 3 VALU
+                // instructions per score here, ~400 cycles per 16-query tile)
+                const f16 h0 = (f16)a0[r], h1 = (f16)a1[r];
+                ph[u][r] = h0; ph[u][4 + r] = h1;
+                if (SPLIT) { pl[u][r] = (f16)(a0[r] - (float)h0); pl[u][4 + r] = (f16)(a1[r] - (float)h1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one 32-key unit at a time: interleaving the units keeps all fp32 exps alive next to P
+        }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -243,17 +275,6 @@ void attention_kernel(AttnParams p) {
         for (int u = 0; u < NU; ++u) {
             if (u + 1 < NU) load_v(u + 1, (u + 1) & 1);
             KEEP_MEM_BARRIER();
-            f16x8 ph, pl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a0 = s[2 * u][r];
-                const float a1 = (2 * u + 1 < NT) ? s[(2 * u + 1 < NT) ? 2 * u + 1 : 0][r] : 0.f;
-                // probabilities lie in [0, 1]: no saturation needed (the clamp of split_f16 was 2 of the 3 VALU
-                // instructions per score here, ~400 cycles per 16-query tile)
-                const f16 h0 = (f16)a0, h1 = (f16)a1;
-                ph[r] = h0; ph[4 + r] = h1;
-                if (SPLIT) { pl[r] = (f16)(a0 - (float)h0); pl[4 + r] = (f16)(a1 - (float)h1); }
-            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const f16x4 v0 = va[u & 1][dt][0], v1 = va[u & 1][dt][1];
@@ -261,13 +282,18 @@ void attention_kernel(AttnParams p) {
                 if (SPLIT) {
                     const f16x4 w0 = vb[u & 1][dt][0], w1 = vb[u & 1][dt][1];
                     const f16x8 vl = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pl, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[u], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pl[u], o[dt], 0, 0, 0);
                 }
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph[u], o[dt], 0, 0, 0);
             }
         }
 #undef KEEP_MEM_BARRIER
+        // The prefetched Q fragments are "used" here, BEFORE this tile's stores go out: the compiler puts its s_waitcnt for them at their
+        // first use, and at the top of the next tile that wait would also drain the stores just issued (one in-order counter).  Here only the Q
+        // loads themselves are outstanding, and they were issued a whole tile ago.
+        asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));
+        if (SPLIT) asm volatile("" : "+v"(qln[0]), "+v"(qln[1]));
         if (q < nq) {
             const int mrow = (int)(tok0 + q);
 #pragma unroll
@@ -276,7 +302,8 @@ void attention_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f16 hh, ll; split_f16(o[dt][r] * inv, hh, ll); oh[r] = hh; ol[r] = ll; }
                 const int col = h * HD + dt * 16 + g * 4;
-                const int64_t oo = p.out_kt > 0 ? blk_off(mrow, col, p.out_kt) : (int64_t)mrow * D + col;
+                const unsigned oo = p.out_kt > 0 ? ((unsigned)(mrow >> 8) * (unsigned)p.out_kt + (unsigned)(col >> 5)) * 8192u + (unsigned)(((mrow & 255) << 5) + (col & 31))
+                                                 : (unsigned)mrow * (unsigned)D + (unsigned)col;       // blk_off (common.h) in 32 bits
                 *reinterpret_cast<f16x4*>(p.out_hi + oo) = oh;
                 if (SPLIT) *reinterpret_cast<f16x4*>(p.out_lo + oo) = ol;
             }
@@ -320,6 +347,8 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
 #endif
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
+    // 32-bit lane offsets inside the kernel: qkv rows of one (batch) slice and the whole output plane (padded to 256 rows) stay below 2^31 elements
+    if ((int64_t)p.ntok * 3 * p.heads * HD >= (1ll << 31) || ((int64_t)p.batch * p.ntok + 255) / 256 * 256 * p.heads * HD >= (1ll << 31)) return -1;
     if (p.split) {
         if (nt <= 4) return launch_one<4, true, 4>(p, s);
         if (nt <= 8) return launch_one<8, true, 4>(p, s);
