@@ -14,13 +14,15 @@ ops = Ops("cuda:0")
 ops.set_option("gemm_impl", 256)
 ops.set_option("gemm_dbg", 1)
 COMP = False
+M = 50432
 for a in sys.argv[1:]:
     k, v = a.split("=")
-    if k == "comp":              # comp=1: compensated launches; stamp 1 then marks the end of the fp16 phase, "loop" below is the MX-fp4 phase
+    if k == "M":                 # rows: 50 432 = 256 tiles x 197 tokens (default); M=4096 leaves most CUs idle (is an epilogue bound by the whole chip's HBM rate?)
+        M = int(v)
+    elif k == "comp":              # comp=1: compensated launches; stamp 1 then marks the end of the fp16 phase, "loop" below is the MX-fp4 phase
         COMP = bool(int(v))
     else:
         ops.set_option(k, float(v))
-M = 50432
 for name, N, K, epi in (("qkv", 3072, 1024, EPI_F16), ("proj", 1024, 1024, EPI_RESID_LS), ("fc1", 4096, 1024, EPI_GELU_F16), ("fc2", 1024, 4096, EPI_RESID_LS)):
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.03; b = torch.zeros(N, device="cuda")
     ls = torch.ones(N, device="cuda"); r = torch.randn(M, N, device="cuda") if epi == EPI_RESID_LS else None
