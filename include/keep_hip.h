@@ -106,6 +106,9 @@ int keep_bert_layers(keep_handle* h);
  *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 320, 0 never).  The two GEMM paths agree to rounding, each is bit-reproducible
  *   "gemm_splitk_tiles"  a larger call whose 256x256 tiling has fewer tiles than this (default 64, 0 never) is cut into
  *                     K slices with fp32 partials + the same reduce/epilogue kernel (8-16 tiles per call: -16..-26 %)
+ *   "gemm_persistent" 1 (default): a plain (one fp16 pass, hi-only output) 256x256 GEMM with more tiles than the device has CUs runs as one
+ *                     workgroup per CU walking the tile list, the next tile's first three K steps staged under the epilogue; 0: one
+ *                     tile per workgroup.  Bit-identical results either way.
  *   "sgemv_m"         same for the few-row fp32 kernel of the projection head / pooler / similarity (default 16)
  *   "ln_impl"         1 (default) LayerNorm with LDS-transposed K-blocked stores | 0 per-row stores
  *   "attn_waves"      wavefronts per attention workgroup, 8 (default) | 4

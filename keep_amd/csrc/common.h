@@ -77,6 +77,8 @@ struct KeepTune {
     int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
     int ln_impl = 1;             // 1: LDS-transposed blk stores; 0: per-row stores
     int attn_waves = 8;          // wavefronts per attention workgroup for 13/16-tile sequences (4 or 8)
+    int gemm_persistent = 1;     // 1: plain 256x256 GEMMs with more tiles than CUs run as one workgroup per CU walking the tile list, the next tile's
+                                 //    first three K steps prefetched under the epilogue (0: one tile per workgroup; n > 1: n workgroups, experiments)
     int gemm_ablate = 0;         // diagnostics (KEEP_DIAGNOSTICS builds only)
     long long* dbg = nullptr;    // diagnostics: per-workgroup shader-clock stamps
 };

@@ -920,6 +920,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
 #ifdef KEEP_EXPERIMENTS
     else if (n == "w_direct") { t.w_direct = v ? 1 : 0; }
 #endif
+    else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
     else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
     else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); t.sgemv_m = v; }
     else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); t.gemm_skinny_m = v; }
@@ -966,6 +967,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "gemm_skinny_m") return t.gemm_skinny_m;
     if (n == "sgemv_m") return t.sgemv_m;
     if (n == "gemm_splitk_tiles") return t.gemm_splitk_tiles;
+    if (n == "gemm_persistent") return t.gemm_persistent;
     if (n == "ln_impl") return t.ln_impl;
     if (n == "attn_waves") return t.attn_waves;
     if (n == "lane_skew") return h->lane_skew;

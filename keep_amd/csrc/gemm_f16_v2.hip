@@ -62,15 +62,21 @@ constexpr int V2_SC2 = 2048;
 constexpr int V2_NST2 = 4;
 constexpr int V2_SC2_BASE = V2_NST2 * V2_ST2;
 constexpr int V2_G2 = 5;             // phase-2 DMA instructions per wave per chunk
+constexpr int V2_PERS_LDS = 160 * 1024;   // persistent kernel: 3 prefetched stages (96 KiB) + 8 epilogue slabs of 8 KiB: all of the CU's LDS
 
 // WD ("W direct", -DKEEP_EXPERIMENTS builds only): the W fragments come straight from global memory into registers
 // (fragment-ordered plane, common.h frag_off) and only A goes through the LDS ring: half of the LDS-DMA writes and a third of the
 // ds_read traffic of a K step gone.  Built because ablations that dropped W's LDS traffic ran 17-19 % faster -- which turned out to be
 // the zero / stale operands those ablations feed the MFMAs (the part is power-limited: low-entropy operands raise its clock).  With real
 // loads the variant is bit-identical and exactly as fast as the two-operand loop.  Kept as the record of that.
-template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP = false, bool WD = false>
+// PERS ("persistent"): one workgroup per CU walks the tile sequence with stride gridDim.x and stages the first three K steps of its NEXT tile into the
+// ring stages that retire during the last steps of the current one, so they land while the epilogue runs (which then bounces through the
+// fourth stage and the 32 KiB of LDS behind the ring).  Same arithmetic, same tile order per XCD (tile t and t + 256 map to the same XCD).
+template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP = false, bool WD = false, bool PERS = false>
 __global__ __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BN, WM, WN))
 void gemm_f16_v2_kernel(GemmParams p) {
+    static_assert(!PERS || (BN == 256 && NSTAGE == 4 && !COMP && !WD && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_RESID_LS)),
+                  "the persistent walk is written for the plain 256x256 / 4-stage kernel");
     constexpr int V2_THREADS = WM * WN * 64;
     constexpr int BM = V2_BM, BK = V2_BK;
     constexpr int TM = BM / WM / 32;            // MFMA tiles per wave along m
@@ -99,7 +105,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int ntn = p.N / BN;
     const int mtn = (p.M + BM - 1) / BM;
     // split-K (EPI_PARTIAL): the grid is the tile sequence repeated once per K slice
-    const int nwg = (EPI == EPI_PARTIAL) ? ntn * mtn : (int)gridDim.x;
+    const int nwg = (EPI == EPI_PARTIAL || PERS) ? ntn * mtn : (int)gridDim.x;
     const int zsplit = (EPI == EPI_PARTIAL) ? (int)blockIdx.x / nwg : 0;
     const int bidx = (EPI == EPI_PARTIAL) ? (int)blockIdx.x - zsplit * nwg : (int)blockIdx.x;
     constexpr int BW = 2048 / BN;             // band of n-tiles that share an A panel on one XCD (8 tiles of 256: measured 2.5 % better than 4 on fc1)
@@ -118,8 +124,8 @@ void gemm_f16_v2_kernel(GemmParams p) {
     };
     int tm, tn;
     tile_of(bidx, tm, tn);
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;
+    int m0 = tm * BM;
+    int n0 = tn * BN;
 
     const int swz_mask = (p.ablate & 4) ? 0 : 3;     // diagnostics: ablate&4 disables the swizzle on both sides
     // ---- DMA source offsets.  Operands are in blk layout (common.h): the 256 x 32 slice of one operand
@@ -139,8 +145,12 @@ void gemm_f16_v2_kernel(GemmParams p) {
         const int row = L / SLOTS, c = (L % SLOTS) ^ v2_swz(row, swz_mask);
         w_off[r] = ((n0 & 255) + row) * BK + c * 8;
     }
-    const int64_t a_tile = (int64_t)(m0 >> 8) * KT * 8192;
-    const int64_t w_tile = (int64_t)(n0 >> 8) * KT * 8192;
+    int64_t a_tile = (int64_t)(m0 >> 8) * KT * 8192;
+    int64_t w_tile = (int64_t)(n0 >> 8) * KT * 8192;
+    // persistent walk: the tile after this one (same workgroup), whose first K steps are staged from the tail of the current K loop
+    int tile_cur = bidx, m0_n = 0, n0_n = 0;
+    int64_t a_tile_n = 0, w_tile_n = 0;
+    bool has_next = false, first_tile = true;
 
     int kt0 = 0, ktiles = KT;
     if (EPI == EPI_PARTIAL) {
@@ -173,17 +183,43 @@ void gemm_f16_v2_kernel(GemmParams p) {
         for (int r = 0; r < B_ROUNDS; ++r)
             __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
     };
+    auto stage_next = [&](int kt, int buf) {             // PERS: K step kt of the NEXT tile (one fp16 pass, no K split)
+        const f16* ab = p.a_hi + a_tile_n + (int64_t)kt * 8192;
+        const f16* wb = p.w_hi + w_tile_n + (int64_t)kt * 8192;
+        f16* sa = lds + buf * BUF_ELEMS;
+        f16* sw = sa + BM * BK;
+        // the lane offsets go through an empty asm so that the addresses are formed here (scalar base + 32-bit lane offset) and not hoisted out
+        // of the K loop as 64-bit lane addresses (they are invariant in it): that costs 32 registers the kernel does not have
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r) {
+            int o = a_off[r];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + o), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
+        }
+#pragma unroll
+        for (int r = 0; r < B_ROUNDS; ++r) {
+            int o = w_off[r];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gptr_t)(wb + o), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
+        }
+    };
 
     f32x16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     long long t_start = 0, t_first = 0, t_loop = 0;
     if (p.dbg) t_start = __builtin_readcyclecounter();
+  for (;;) {                                               // one pass per tile; a non-persistent kernel leaves after the first
+    if constexpr (PERS) {
+        // The tail of the K loop ALWAYS stages three K steps of "the next tile" (for the last tile of this workgroup: of the tile itself again,
+        // 96 KiB nobody reads), so that the K loop has one shape and one set of vmcnt counts: a branch around those steps, with 128
+        // accumulators live across it, made the register allocator shuffle accumulators through scratch at the join.
+        const int tnx = tile_cur + (int)gridDim.x;
+        has_next = tnx < nwg;
+        int tm2, tn2;
+        tile_of(has_next ? tnx : tile_cur, tm2, tn2);
+        m0_n = tm2 * BM; n0_n = tn2 * BN;
+        a_tile_n = (int64_t)(m0_n >> 8) * KT * 8192;
+        w_tile_n = (int64_t)(n0_n >> 8) * KT * 8192;
+    }
     // ---- software-pipelined main loop -------------------------------------------------------------
     // Per K tile (32 deep) a wave runs two groups of TN*TM MFMAs, on fragment sets R0 (k 0..15) and R1
     // (k 16..31).  The single barrier of a step sits BETWEEN the two groups:
@@ -259,6 +295,12 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // The loads are inline asm (hipcc would otherwise drain the DMA queue with vmcnt(0) at the first use of a register load); the
     // wait statements name the destination registers so nothing is scheduled across them.
     static_assert(BN == 256 && WM == 2 && WN == 4 && NSTAGE == 4, "W-direct loop is written for the 256x256 / 2x4 waves / 4-stage tile");
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     constexpr int A_STAGE = BM * BK;                       // f16 elements
     const int S = KT;                                      // steps (nseg == 1, no K split); even and >= 4 (checked by the launcher)
     f16x8 fwa0[TN], fwa1[TN], fwb0[TN], fwb1[TN];          // W fragments: sets a (even steps) and b (odd steps), k-half 0 and 1
@@ -337,13 +379,27 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #undef KEEP_LOADW
   } else {
 
+    if (PERS && p.dbg && !first_tile) t_start = __builtin_readcyclecounter();      // diagnostics: the stamps describe the workgroup's LAST tile
+    if (!PERS || first_tile) {
 #pragma unroll
-    for (int t = 0; t < NSTAGE - 1; ++t)
-        if (t < steps) stage(t, t);
-    if (steps >= NSTAGE - 1) wait_vmcnt<G * (NSTAGE - 2)>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (p.dbg) t_first = __builtin_readcyclecounter();
-    if (NSTAGE - 1 < steps) stage(NSTAGE - 1, NSTAGE - 1);
+        for (int t = 0; t < NSTAGE - 1; ++t)
+            if (t < steps) stage(t, t);
+        if (steps >= NSTAGE - 1) wait_vmcnt<G * (NSTAGE - 2)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (p.dbg) t_first = __builtin_readcyclecounter();
+        if (NSTAGE - 1 < steps) stage(NSTAGE - 1, NSTAGE - 1);
+    } else {
+        // K steps 0, 1 and 2 of this tile were staged from the previous tile's last three steps and landed under its epilogue (waited for and
+        // published at the end of it); step 3 goes out now, into the stage the epilogue has just left
+        stage(3, 3);
+        if (p.dbg) t_first = t_start;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     read_frags(0, 0, fw0, fa0);
 
     // steady state: every step but the last NSTAGE-1 has a full ring in flight
@@ -365,6 +421,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
         KEEP_PIN();
         if (s + NSTAGE < steps) stage(s + NSTAGE, s % NSTAGE);
         else if constexpr (PRE) stage2(0, 0);               // s == steps - NSTAGE: stage 0 is free
+        else if constexpr (PERS) stage_next(0, 0);             // s == steps - NSTAGE: the next tile's K step 0 -> stage 0
         read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
         KEEP_PIN();
         mfma_tail(fw1, fa1);
@@ -395,6 +452,13 @@ void gemm_f16_v2_kernel(GemmParams p) {
         KEEP_DRAIN_STEP(G + V2_G2, stage2(1, 1))
         ++s;
         KEEP_DRAIN_STEP(2 * V2_G2, stage2(2, 2))
+        ++s;
+    } else if constexpr (PERS) {
+        // step steps-3 needs tile steps-2: younger are tile steps-1 and the next tile's step 0; step steps-2 needs tile steps-1: younger are the
+        // next tile's steps 0 and 1
+        KEEP_DRAIN_STEP(2 * G, stage_next(1, 1))
+        ++s;
+        KEEP_DRAIN_STEP(2 * G, stage_next(2, 2))
         ++s;
     } else {
         for (; s < steps - 1; ++s) KEEP_DRAIN_STEP(0, (void)0)          // wait for everything that is left
@@ -525,7 +589,15 @@ void gemm_f16_v2_kernel(GemmParams p) {
     constexpr int PITCH16 = WN_COLS + 8;             // fp16 elements: 144-byte rows keep ds_read_b128 aligned
     constexpr int SLAB_FLOATS = ((32 * PITCH > 32 * PITCH16 ? 32 * PITCH : 32 * PITCH16) + 63) / 64 * 64 + 96;   // fp32 slab or fp16 hi+lo slabs (2400 for 64 columns)
     static_assert(SLAB_FLOATS * 4 * WM * WN <= NSTAGE * (V2_BM + BN) * V2_BK * 2, "epilogue slabs must fit the LDS ring");
-    float* slab = reinterpret_cast<float*>(smem_raw) + wave * SLAB_FLOATS;
+    // persistent: stages 0..2 hold the next tile's first K steps, the slabs live in stage 3 + the 32 KiB of LDS behind the ring: 8 KiB per wave.
+    // That is exactly 32 x 64 fp32 without padding -- the 16-byte chunks of row r are rotated by r instead (same bank pattern as the padded
+    // rows) -- and one fp16 plane with padding: the persistent kernel is launched for hi-only outputs.
+    constexpr int SLAB_BASE = PERS ? 3 * (V2_BM + BN) * V2_BK * 2 : 0;
+    constexpr int SLAB_STRIDE = PERS ? 2048 : SLAB_FLOATS;                // floats per wave
+    static_assert(!PERS || (SLAB_BASE + SLAB_STRIDE * 4 * WM * WN <= V2_PERS_LDS && 32 * PITCH16 * 2 <= SLAB_STRIDE * 4), "persistent epilogue slabs must fit behind the three prefetched stages");
+    float* slab = reinterpret_cast<float*>(smem_raw + SLAB_BASE) + wave * SLAB_STRIDE;
+    auto slab_off = [&](int r, int col) { return PERS ? r * 64 + ((((col >> 2) + r) & 15) << 2) : r * PITCH + col; };   // col: multiple of 4
+    const bool want_lo = !PERS && (p.out_lo || p.out_q);
     constexpr bool F16_OUT = (EPI == EPI_F16 || EPI == EPI_GELU_F16);
     constexpr int CPL = F16_OUT ? 8 : 4;             // columns per lane on the way out
     constexpr int LPR = WN_COLS / CPL;               // lanes per row
@@ -590,7 +662,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     split_f16(b[1], hh, ll); h[3] = hh; l[3] = ll;
                     const int so = frow * PITCH16 + i * 32 + 8 * rg + 4 * fhi;
                     *reinterpret_cast<f16x4*>(slab_hi + so) = h;
-                    if (p.out_lo || p.out_q) *reinterpret_cast<f16x4*>(slab_lo + so) = l;
+                    if (want_lo) *reinterpret_cast<f16x4*>(slab_lo + so) = l;
                 }
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
@@ -600,7 +672,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                 if (m < p.M) {
                     const int64_t o = p.out_kt > 0 ? blk_off(m, ncol, p.out_kt) : (int64_t)m * p.N + ncol;
                     *reinterpret_cast<f16x8*>(p.out_hi + o) = h;
-                    if (p.out_lo || p.out_q) {
+                    if (want_lo) {
                         const f16x8 l = *reinterpret_cast<const f16x8*>(slab_lo + r * PITCH16 + ocol);
                         if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = l;
                         // this GEMM's N is the consumer's K: 8 lanes cover the wave's 64 columns = two MX blocks of 4 lanes each
@@ -616,7 +688,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
-                    *reinterpret_cast<f32x4*>(slab + frow * PITCH + i * 32 + 8 * rg + 4 * fhi) = v;
+                    *reinterpret_cast<f32x4*>(slab + slab_off(frow, i * 32 + 8 * rg + 4 * fhi)) = v;
                 }
             // the residual rows of pass j+1 are requested before pass j is finished, so the read latency of
             // the read-modify-write hides behind the previous pass (res2 / oo2 are double-buffered by parity of j)
@@ -624,7 +696,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int r = it * RPI + orow_in;
-                f32x4 x = *reinterpret_cast<const f32x4*>(slab + r * PITCH + ocol);
+                f32x4 x = *reinterpret_cast<const f32x4*>(slab + slab_off(r, ocol));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] += bias4[0][e];
@@ -637,6 +709,18 @@ void gemm_f16_v2_kernel(GemmParams p) {
             }
         }
     }
+    if constexpr (!PERS) break;
+    else {
+        if (!has_next) { wait_vmcnt<0>(); break; }          // the last tile's (unused) prefetch must not outlive the workgroup's LDS
+        // The next tile's K steps 0..2 were issued a whole epilogue ago; vmcnt(0) here waits, at most, for the acknowledgement of this wave's last
+        // stores.  The barrier publishes the staged data and says every wave is done with its slab (stage 3 may be overwritten).
+        wait_vmcnt<0>();
+        __syncthreads();
+        m0 = m0_n; n0 = n0_n; a_tile = a_tile_n; w_tile = w_tile_n;
+        tile_cur += (int)gridDim.x;
+        first_tile = false;
+    }
+  }
     if (p.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
@@ -656,6 +740,29 @@ bool v2_opt_in_lds(K kernel, size_t bytes) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
     if (dev < 64) done |= 1ull << dev;
     return true;
+}
+
+// number of CUs of the current device (the persistent kernel's grid)
+static int v2_num_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
+template <int EPI>
+int launch_v2_pers(const GemmParams& p, hipStream_t s) {
+    auto kernel = &gemm_f16_v2_kernel<256, 2, 4, 4, EPI, false, false, true>;
+    if (!v2_opt_in_lds(kernel, (size_t)V2_PERS_LDS)) return -2;
+    const int tiles = (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM);
+    int cus = v2_num_cus();
+    if (p.tune && p.tune->gemm_persistent > 1 && p.tune->gemm_persistent < cus) cus = p.tune->gemm_persistent;     // experiment: fewer workgroups than CUs
+    hipLaunchKernelGGL(kernel, dim3(tiles < cus ? tiles : cus), dim3(512), (size_t)V2_PERS_LDS, s, p);
+    return 0;
 }
 
 template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP, bool WD = false>
@@ -715,6 +822,12 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
     if (wd && epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, false, true>(p, s);
     if (wd && epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, false, true>(p, s);
 #endif
+    if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
+        (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > v2_num_cus()) {
+        if (epi == EPI_F16) return launch_v2_pers<EPI_F16>(p, s);
+        if (epi == EPI_GELU_F16) return launch_v2_pers<EPI_GELU_F16>(p, s);
+        if (epi == EPI_RESID_LS) return launch_v2_pers<EPI_RESID_LS>(p, s);
+    }
     if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
     if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
 #ifdef KEEP_EXPERIMENTS

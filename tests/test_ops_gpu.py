@@ -172,6 +172,33 @@ def test_mlp_block_modes(ops, D, F, M):
     assert err[2] < 0.25 * err[0]
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(16640, 1024, 1024, EPI_RESID_LS), (8300, 3072, 1024, EPI_F16), (9000, 4096, 1024, EPI_GELU_F16),
+                                       (16900, 1024, 4096, EPI_RESID_LS), (66000, 1024, 256, EPI_F16)])
+def test_persistent_gemm_is_bit_identical_to_one_tile_per_workgroup(M, N, K, epi):
+    """gemm_persistent=1: one workgroup per CU walks the tile list and stages the next tile's first three K steps from the tail of the
+    current K loop (they land under the epilogue, which then bounces through what is left of the LDS).  Same products in the same order:
+    every output bit must match the one-tile-per-workgroup launch -- on full tiles, on the ragged last row tile, with 2 to 4 tiles per
+    workgroup, and with the shortest K the path accepts (8 steps)."""
+    a, w, b = rand(M, K, seed=51), rand(N, K, seed=52, std=0.04), rand(N, seed=53, std=0.1)
+    ls = torch.rand(N, generator=torch.Generator().manual_seed(54)) * 0.45 + 0.05
+    resid = rand(M, N, seed=55)
+    kw = dict(ls=ls, resid=resid) if epi == EPI_RESID_LS else {}
+    from keep_amd.ops import Ops
+    outs = []
+    for pers in (0, 1, 0, 1):
+        o = Ops("cuda:0")                      # options are per handle: a fresh one per setting leaves the session's handle alone
+        o.set_option("gemm_persistent", pers)
+        outs.append(o.linear(a, w, b, epi, False, **kw).cpu())
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])       # each path is deterministic
+    assert torch.equal(outs[0], outs[1]), f"max diff {(outs[0] - outs[1]).abs().max().item():.3e}"
+    ref = a.double() @ w.double().t() + b.double()
+    if epi == EPI_RESID_LS:
+        ref = resid.double() + ls.double() * ref
+    elif epi == EPI_GELU_F16:
+        ref = gelu64(ref)
+    assert (outs[1].double() - ref).abs().max().item() < 0.05
+
+
 @pytest.mark.parametrize("M,N,K,epi,split", [(394, 3072, 1024, EPI_F16, 0), (1182, 4096, 1024, EPI_GELU_F16, 0), (2048, 1024, 4096, EPI_RESID_LS, 0),
                                              (700, 1024, 1024, EPI_RESID_LS, 0), (1000, 256, 192, EPI_F16, 0), (512, 768, 3072, EPI_RESID_LS, 2),
                                              (1576, 4096, 1024, EPI_GELU_F16, 2), (300, 256, 128, EPI_F16, 0)])

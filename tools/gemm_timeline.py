@@ -30,6 +30,7 @@ for name, N, K, epi in (("qkv", 3072, 1024, EPI_F16), ("proj", 1024, 1024, EPI_R
         ops.linear(a, w, b, epi, 2 if COMP else False, ls=ls, resid=r)
     nb = (M // 256) * (N // 256)
     t = ops.debug_timeline(nb).astype(np.float64)
+    t = t[t[:, 3] > 0]          # a persistent launch (gemm_persistent=1) stamps one row per workgroup, describing its LAST tile
     t0 = t[:, 0].min()
     dur = t[:, 3].max() - t0
     pro, loop, epi_t, tot = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]
