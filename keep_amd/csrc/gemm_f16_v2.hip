@@ -160,11 +160,21 @@ void gemm_f16_v2_kernel(GemmParams p) {
     }
     const int steps = ktiles * p.nseg;
 
-    auto stage = [&](int s, int buf) {
-        const int seg = s / ktiles;
-        const int kt = kt0 + (s - seg * ktiles);
-        const f16* ab = ((seg == 1) ? p.a_lo : p.a_hi) + a_tile + (int64_t)kt * 8192;
-        const f16* wb = ((seg == 2) ? p.w_lo : p.w_hi) + w_tile + (int64_t)kt * 8192;
+    // stage() is called for s = 0, 1, 2, ... in order, so the operand pointers of "the next step to stage" are carried along (a step moves
+    // them 16 KiB; a segment boundary of the split product swaps the planes) instead of being derived from s: the division and selects
+    // that cost were ~30 dependent scalar instructions in the middle of every K step, in a wave that issues no MFMA meanwhile.
+    const f16* st_a = p.a_hi + a_tile + (int64_t)kt0 * 8192;
+    const f16* st_w = p.w_hi + w_tile + (int64_t)kt0 * 8192;
+    int st_left = ktiles, st_seg = 0;
+    auto stage = [&](int, int buf) {
+        const f16* ab = st_a;
+        const f16* wb = st_w;
+        st_a += 8192; st_w += 8192;
+        if (--st_left == 0) {
+            ++st_seg; st_left = ktiles;
+            st_a = ((st_seg == 1) ? p.a_lo : p.a_hi) + a_tile + (int64_t)kt0 * 8192;
+            st_w = ((st_seg == 2) ? p.w_lo : p.w_hi) + w_tile + (int64_t)kt0 * 8192;
+        }
         f16* sa = lds + buf * BUF_ELEMS;
         f16* sw = sa + BM * BK;
 #pragma unroll
@@ -717,6 +727,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
         wait_vmcnt<0>();
         __syncthreads();
         m0 = m0_n; n0 = n0_n; a_tile = a_tile_n; w_tile = w_tile_n;
+        st_a = p.a_hi + a_tile + 3 * 8192; st_w = p.w_hi + w_tile + 3 * 8192; st_left = ktiles - 3;    // K steps 0..2 of the new tile are in the ring
         tile_cur += (int)gridDim.x;
         first_tile = false;
     }
