@@ -20,7 +20,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkeep_hip.so")
 SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
 EXPERIMENT_SOURCES = ["gemm_f16_v3.hip"]      # compiled only with KEEP_BUILD_DEFINES=-DKEEP_EXPERIMENTS (measured-negative variants)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
+# -falign-loops=64: the hot loops start on an instruction-cache line.  Without it a functionally identical edit elsewhere in a kernel moved the
+# K loop of the GEMM by a few dwords and the whole encoder by up to 3 % (measured: DESIGN.md section 4); with it +0.5 % and reproducible.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-falign-loops=64", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value",
+         "-Wno-unused-result"]
 
 
 def hipcc() -> str:

@@ -170,28 +170,38 @@ void gemm_f16_v2_kernel(GemmParams p) {
         const f16* ab = st_a;
         const f16* wb = st_w;
         st_a += 8192; st_w += 8192;
-        if (--st_left == 0) {
+        if (!(PERS || COMP) && --st_left == 0) {             // (persistent and compensated launches are single-pass: no segment boundary, no branch)
             ++st_seg; st_left = ktiles;
             st_a = ((st_seg == 1) ? p.a_lo : p.a_hi) + a_tile + (int64_t)kt0 * 8192;
             st_w = ((st_seg == 2) ? p.w_lo : p.w_hi) + w_tile + (int64_t)kt0 * 8192;
         }
         f16* sa = lds + buf * BUF_ELEMS;
         f16* sw = sa + BM * BK;
+        // lane offsets through an empty asm: the address is then formed at the instruction as scalar base + 32-bit lane offset.  Left to itself
+        // the compiler strength-reduces the loop to 64-bit lane pointers + a running scalar offset: 4 v_lshl_add_u64 per K step and the
+        // vector-address form of the DMA instruction -- measured 3.7 % slower end to end.
+        unsigned ao[A_ROUNDS], wo[B_ROUNDS];                 // BYTE offsets, unsigned: zero-extended lane offset + scalar base is the form that maps to the instruction
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r) { ao[r] = (unsigned)a_off[r] * 2u; asm volatile("" : "+v"(ao[r])); }
+#pragma unroll
+        for (int r = 0; r < B_ROUNDS; ++r) { wo[r] = (unsigned)w_off[r] * 2u; asm volatile("" : "+v"(wo[r])); }
+        const char* abb = reinterpret_cast<const char*>(ab);
+        const char* wbb = reinterpret_cast<const char*>(wb);
 #pragma unroll
         for (int r = 0; r < A_ROUNDS; ++r)
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab + a_off[r]), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(abb + ao[r]), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
 #ifdef KEEP_DIAGNOSTICS
         // what would a kernel gain that did not stream W through LDS?  ablate & 16: same number of DMA instructions, a quarter of the bytes
         if (p.ablate & 16) {
 #pragma unroll
             for (int r = 0; r < B_ROUNDS; ++r)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 4, 0, KEEP_W_AUX);
+                __builtin_amdgcn_global_load_lds((gptr_t)(wbb + wo[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 4, 0, KEEP_W_AUX);
             return;
         }
 #endif
 #pragma unroll
         for (int r = 0; r < B_ROUNDS; ++r)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wb + w_off[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wbb + wo[r]), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
     };
     auto stage_next = [&](int kt, int buf) {             // PERS: K step kt of the NEXT tile (one fp16 pass, no K split)
         const f16* ab = p.a_hi + a_tile_n + (int64_t)kt * 8192;
@@ -202,15 +212,15 @@ void gemm_f16_v2_kernel(GemmParams p) {
         // of the K loop as 64-bit lane addresses (they are invariant in it): that costs 32 registers the kernel does not have
 #pragma unroll
         for (int r = 0; r < A_ROUNDS; ++r) {
-            int o = a_off[r];
+            unsigned o = (unsigned)a_off[r] * 2u;
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((gptr_t)(ab + o), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(ab) + o), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
         }
 #pragma unroll
         for (int r = 0; r < B_ROUNDS; ++r) {
-            int o = w_off[r];
+            unsigned o = (unsigned)w_off[r] * 2u;
             asm volatile("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((gptr_t)(wb + o), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(wb) + o), (lptr_t)(sw + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_W_AUX);
         }
     };
 
@@ -413,29 +423,39 @@ void gemm_f16_v2_kernel(GemmParams p) {
     read_frags(0, 0, fw0, fa0);
 
     // steady state: every step but the last NSTAGE-1 has a full ring in flight
-    int s = 0;
-    for (; s < steps - (NSTAGE - 1); ++s) {
-        // group 0 on R0[s]; R1[s] (same stage, already landed) is fetched under it
-        mfma_head(fw0, fa0);
-        KEEP_PIN();
-        read_frags(s % NSTAGE, 1, fw1, fa1);
-        KEEP_PIN();
-        mfma_tail(fw0, fa0);
-        KEEP_PIN();
-        wait_vmcnt<G * (NSTAGE - 2)>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        KEEP_PIN();
-        // group 1 on R1[s]; DMA for tile s+NSTAGE and R0[s+1] are issued under it
-        mfma_head(fw1, fa1);
-        KEEP_PIN();
-        if (s + NSTAGE < steps) stage(s + NSTAGE, s % NSTAGE);
-        else if constexpr (PRE) stage2(0, 0);               // s == steps - NSTAGE: stage 0 is free
-        else if constexpr (PERS) stage_next(0, 0);             // s == steps - NSTAGE: the next tile's K step 0 -> stage 0
-        read_frags((s + 1) % NSTAGE, 0, fw0, fa0);
-        KEEP_PIN();
-        mfma_tail(fw1, fa1);
+#define KEEP_STEADY_STEP(ISSUE)                                                                                                    \
+    {                                                                                                                              \
+        /* group 0 on R0[s]; R1[s] (same stage, already landed) is fetched under it */                                             \
+        mfma_head(fw0, fa0);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        read_frags(s % NSTAGE, 1, fw1, fa1);                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        mfma_tail(fw0, fa0);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        wait_vmcnt<G * (NSTAGE - 2)>();                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                              \
+        KEEP_PIN();                                                                                                                \
+        /* group 1 on R1[s]; DMA for tile s+NSTAGE and R0[s+1] are issued under it */                                              \
+        mfma_head(fw1, fa1);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        ISSUE;                                                                                                                     \
+        read_frags((s + 1) % NSTAGE, 0, fw0, fa0);                                                                                 \
+        KEEP_PIN();                                                                                                                \
+        mfma_tail(fw1, fa1);                                                                                                       \
     }
+    int s = 0;
+    if constexpr (PRE || PERS) {
+        // (the launcher admits these only with steps >= 2 * NSTAGE)  The step that has nothing left to stage for this tile is peeled, so the
+        // hot loop carries no "is there a K step left" branch: every scalar branch in it costs the wave tens of cycles in which it issues nothing
+        for (; s < steps - NSTAGE; ++s) KEEP_STEADY_STEP(stage(s + NSTAGE, s % NSTAGE))
+        if constexpr (PRE) KEEP_STEADY_STEP(stage2(0, 0))              // s == steps - NSTAGE: stage 0 is free -> chunk 0 of the fp4 phase
+        else KEEP_STEADY_STEP(stage_next(0, 0))                        //                                      -> the next tile's K step 0
+        ++s;
+    } else {
+        for (; s < steps - (NSTAGE - 1); ++s) KEEP_STEADY_STEP(if (s + NSTAGE < steps) stage(s + NSTAGE, s % NSTAGE))
+    }
+#undef KEEP_STEADY_STEP
     // drain: fewer tiles in flight
 #define KEEP_DRAIN_STEP(WAIT, AFTER)                                                                                               \
     {                                                                                                                              \
