@@ -284,18 +284,26 @@ void gemm_f16_v2_kernel(GemmParams p) {
         wq = p.w_q + (int64_t)(n0 >> 8) * KT * 8192;
         sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512) + (wave & 3) * 256;     // wave-uniform; lanes add 4 * lane
     }
-    auto stage2 = [&](int c, int buf) {
+    // stage2() is called for chunks 0, 1, 2, ... in order (the first three from the tail of the fp16 loop): running scalar bases, one unsigned
+    // 32-bit lane offset per instruction kept opaque to the optimiser -- otherwise the addresses become 64-bit lane pointers (hoisted out of the
+    // fp16 loop and spilled, or strength-reduced inside the fp4 loop into vector-address DMA instructions + 64-bit VALU adds)
+    const unsigned char* aq_run = aq; const unsigned char* wq_run = wq; const unsigned char* sq_run = sq;
+    auto stage2 = [&](int, int buf) {
         unsigned char* sb = smem_raw + buf * V2_ST2;
-        // scalar base + one 32-bit lane offset per instruction.  The empty asm keeps the offsets from being folded into 64-bit lane
-        // addresses that would be hoisted out of the fp16 loop and held in registers (spilled, in fact) across it.
-        unsigned v16 = tid * 16, v4 = lane * 4;
-        asm volatile("" : "+v"(v16), "+v"(v4));
+        unsigned v4 = lane * 4;
+        asm volatile("" : "+v"(v4));
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(aq + ((int64_t)c * 16384 + r * 8192) + v16), (lptr_t)(sb + (r * 512 + wave * 64) * 16), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wq + ((int64_t)c * 16384 + r * 8192) + v16), (lptr_t)(sb + 16384 + (r * 512 + wave * 64) * 16), 16, 0, 0);
+            // one opaque copy of the lane offset per instruction: a shared one gets added to the running base ONCE, as a 64-bit lane pointer
+            unsigned va = tid * 16, vw = tid * 16;
+            const unsigned char* ab = aq_run + r * 8192;
+            const unsigned char* wb = wq_run + r * 8192;
+            asm volatile("" : "+v"(va), "+v"(vw), "+s"(ab), "+s"(wb));      // (and the scalar sums stay scalar)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + va), (lptr_t)(sb + (r * 512 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wb + vw), (lptr_t)(sb + 16384 + (r * 512 + wave * 64) * 16), 16, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds((gptr_t)(sq + (int64_t)c * 1024 + v4), (lptr_t)(smem_raw + V2_SC2_BASE + buf * V2_SC2 + (wave >> 2) * 1024 + (wave & 3) * 256), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(sq_run + v4), (lptr_t)(smem_raw + V2_SC2_BASE + buf * V2_SC2 + (wave >> 2) * 1024 + (wave & 3) * 256), 4, 0, 0);
+        aq_run += 16384; wq_run += 16384; sq_run += 1024;
     };
     // PRE: chunks 0..2 of phase 2 go out from the last fp16 steps, each into the phase-1 stage that step has just retired (chunk c lands in
     // stage c: the launcher admits compensated products only with a step count that is a multiple of the ring depth, K % 128 == 0, and
@@ -539,33 +547,41 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #define KEEP_MX(I, J) \
             acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah); \
             acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
-        for (int c = 0; c < NC; ++c) {
-            const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;
-            const unsigned char* ss = smem_raw + V2_SC2_BASE + (c & (V2_NST2 - 1)) * V2_SC2;
-            const unsigned char* sa = sb + fhi * 8192;                  // this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31
-            const unsigned char* sw = sb + 16384 + fhi * 8192;
-            // native vector type, not HIP's uint4 struct: a struct load carries no alias info, and hipcc then puts an s_waitcnt vmcnt(0)
-            // ("may read what an LDS-DMA in flight writes") in front of it -- which drains the ring on every chunk
-            u32x4 ah[4], al[4], wh[2], wl[2];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                ah[jj] = *reinterpret_cast<const u32x4*>(sa + a_row + jj * 512);
-                al[jj] = *reinterpret_cast<const u32x4*>(sa + 4096 + a_row + jj * 512);
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                wh[ii] = *reinterpret_cast<const u32x4*>(sw + w_row + ii * 512);
-                wl[ii] = *reinterpret_cast<const u32x4*>(sw + 4096 + w_row + ii * 512);
-            }
-            const int sah = *reinterpret_cast<const int*>(ss + asc_off), sal = *reinterpret_cast<const int*>(ss + asc_off + 256);
-            const int swh = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off) >> wsh), swl = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off + 256) >> wsh);
-            if (c + V2_NST2 - 1 < NC) stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1));     // the stage chunk c-1 was read from
-            KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)
-            KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)
-            if (c + V2_NST2 - 1 < NC) wait_vmcnt<G2 * (V2_NST2 - 2)>(); else wait_vmcnt<0>();          // chunk c+1 has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+        // One macro body, two loops (the last three chunks have nothing left to stage): the hot loop has no branch but its back-edge.
+#define KEEP_CHUNK(ISSUE, WAIT)                                                                                                    \
+        {                                                                                                                          \
+            const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;                                                     \
+            const unsigned char* ss = smem_raw + V2_SC2_BASE + (c & (V2_NST2 - 1)) * V2_SC2;                                       \
+            const unsigned char* sa = sb + fhi * 8192;      /* this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31 */            \
+            const unsigned char* sw = sb + 16384 + fhi * 8192;                                                                     \
+            /* native vector type, not HIP's uint4 struct: a struct load carries no alias info, and hipcc then puts an */          \
+            /* s_waitcnt vmcnt(0) ("may read what an LDS-DMA in flight writes") in front of it: the ring drained on every chunk */  \
+            u32x4 ah[4], al[4], wh[2], wl[2];                                                                                      \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                     \
+                ah[jj] = *reinterpret_cast<const u32x4*>(sa + a_row + jj * 512);                                                   \
+                al[jj] = *reinterpret_cast<const u32x4*>(sa + 4096 + a_row + jj * 512);                                            \
+            }                                                                                                                      \
+            _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                                     \
+                wh[ii] = *reinterpret_cast<const u32x4*>(sw + w_row + ii * 512);                                                   \
+                wl[ii] = *reinterpret_cast<const u32x4*>(sw + 4096 + w_row + ii * 512);                                            \
+            }                                                                                                                      \
+            const int sah = *reinterpret_cast<const int*>(ss + asc_off), sal = *reinterpret_cast<const int*>(ss + asc_off + 256);  \
+            const int swh = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off) >> wsh),                                        \
+                      swl = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off + 256) >> wsh);                                  \
+            ISSUE;                                          /* into the stage chunk c-1 was read from */                           \
+            KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)                                                                \
+            KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)                                                                \
+            wait_vmcnt<WAIT>();                             /* chunk c+1 has landed */                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+            __builtin_amdgcn_s_barrier();                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);              /* the peeled bodies must not be interleaved: 52 operand registers each */ \
         }
+        int c = 0;                                          // NC >= 4: compensated products are admitted with K >= 256 only
+        for (; c < NC - (V2_NST2 - 1); ++c) KEEP_CHUNK(stage2(c + V2_NST2 - 1, (c + V2_NST2 - 1) & (V2_NST2 - 1)), G2 * (V2_NST2 - 2))
+        // the last three chunks: a second (rolled) loop -- three straight-line copies of the body made the allocator spill accumulators
+#pragma clang loop unroll(disable)
+        for (; c < NC; ++c) KEEP_CHUNK((void)0, 0)
+#undef KEEP_CHUNK
 #undef KEEP_MX
 #undef KEEP_V8
     }
