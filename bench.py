@@ -36,7 +36,7 @@ from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles    # noq
 
 PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense
 PEAK_HBM_GBS = 8000.0
-DOMINANT_TAG = "vit.fc1"     # gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,*>: [B*197,1024] x [1024,4096], 32 % of the FLOPs
+DOMINANT_TAG = "vit.fc1"     # gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,*> (persistent walk in the plain blocks, fp4 phase in the compensated ones): [B*197,1024] x [1024,4096], 32 % of the FLOPs
 BERT_FLOPS_PER_PROMPT_256 = 45_903_642_624
 DTYPE_NAME = {"fp16": "fp16", "comp": "fp16+mxfp4", "strict": "fp16x3"}
 
@@ -327,7 +327,7 @@ def main():
                 except (OSError, ValueError):
                     traffic = None
         frac_e2e = tiles_per_s / world * vit_flops_per_tile() / (PEAK_F16_TFLOPS * 1e12)
-        roofline = {"bound": "mfma", "kernel": "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,{plain|+mxfp4 phase}> (vit.fc1)",
+        roofline = {"bound": "mfma", "kernel": "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,{persistent plain | +mxfp4 phase}> (vit.fc1)",
                     "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,

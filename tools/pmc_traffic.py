@@ -17,9 +17,9 @@ def mean_per_kernel(path, counter):
 
 fetch = mean_per_kernel(sys.argv[1], "FETCH_SIZE")
 write = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
-TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, false>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>",
-        "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, false>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, false>",
-        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "vit.attn": "attention_kernel<13, false, 8>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
+TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, false, true>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false, false>",
+        "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, false, true>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, false, true>",
+        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false, false>", "vit.attn": "attention_kernel<13, false, 8>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
 out = {}
 for tag, pat in TAGS.items():
     f = [(v, n) for k, (v, n) in fetch.items() if pat in k]
