@@ -374,7 +374,7 @@ int vit_begin(keep_handle* h, VitLane& L) {
                                    find(h, "visual.patch_embed.proj.bias")->f32);
         p.pos = find(h, "visual.pos_embed")->f32;
         p.resid = ws.resid;
-        run_gemm(h, T_VIT_PATCH, p, EPI_PATCH, s, ws.splitk);
+        if (run_gemm(h, T_VIT_PATCH, p, EPI_PATCH, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "patch-embedding GEMM launch failed");
     }
     return KEEP_OK;
 }
@@ -410,7 +410,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         Scope sc(h, T_VIT_QKV, s);
         GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
         p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-        run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk);
+        if (run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "qkv GEMM launch failed");
     }
     mark(1);
     {
@@ -448,6 +448,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         p.ls = b.ls1; p.resid = resid;
         if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
         did = run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
+        if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
     }
     mark(3);
     if (!(did & GEMM_DID_LN) && !skip_ln) {
@@ -462,7 +463,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
             p.out_q = ws.mlp_q; p.out_sc = ws.mlp_sc;
         }
-        if (run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "compensated fc1 launch failed");
+        if (run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "fc1 GEMM launch failed");
     }
     mark(4);
     {
@@ -478,7 +479,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             offer_ln(p, ln);
         }
         const int rc = run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk);
-        if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "compensated fc2 launch failed");
+        if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "fc2 GEMM launch failed");
         L.xn_ready = (rc & GEMM_DID_LN) != 0;
     }
     mark(5);
@@ -535,7 +536,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_QKV, s);
             GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, &b.qkv, M, sp, b.qkv_b);
             p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-            run_gemm(h, T_TXT_QKV, p, EPI_F16, s, ws.splitk);
+            if (run_gemm(h, T_TXT_QKV, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "text qkv GEMM launch failed");
         }
         {
             Scope sc(h, T_TXT_ATTN, s);
@@ -558,6 +559,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             p.resid = ws.resid; p.out_f32 = ws.resid;
             offer_ln(p, ln);
             did = run_gemm(h, T_TXT_OUT, p, EPI_RESID_F32, s, ws.splitk);
+            if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "text attention-output GEMM launch failed");
         }
         if (!(did & GEMM_DID_LN)) {
             Scope sc(h, T_TXT_LN, s);
@@ -567,7 +569,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             Scope sc(h, T_TXT_FFN1, s);
             GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.i, M, sp, b.i_b);
             p.out_hi = ws.mlp_hi; p.out_lo = sp ? ws.mlp_lo : nullptr; p.out_kt = h->bert_F / 32;
-            run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s, ws.splitk);
+            if (run_gemm(h, T_TXT_FFN1, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "text FFN GEMM launch failed");
         }
         ln.gamma = b.ln2w; ln.beta = b.ln2b; ln.out_lo = sp_next ? ws.xn_lo : nullptr;
         {
@@ -576,6 +578,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             p.resid = ws.resid; p.out_f32 = ws.resid;
             offer_ln(p, ln);
             did = run_gemm(h, T_TXT_FFN2, p, EPI_RESID_F32, s, ws.splitk);
+            if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "text FFN GEMM launch failed");
         }
         if (!(did & GEMM_DID_LN)) {
             Scope sc(h, T_TXT_LN, s);

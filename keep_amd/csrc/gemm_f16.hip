@@ -186,8 +186,7 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     if (impl == 2128 || impl == 3256 || impl == 4256 || impl == 5256) { if (launch_gemm_f16_v2(p, epi, impl, s) == 0) return 0; }
 #endif
     if ((impl != 128 && impl != 256) || (impl == 256 && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
-    launch_gemm_f16_v2(p, epi, impl, s);
-    return 0;
+    return launch_gemm_f16_v2(p, epi, impl, s) == 0 ? 0 : -1;      // (-1: shape not covered or the LDS opt-in was refused -- the callers report it)
 }
 
 #ifdef KEEP_EXPERIMENTS

@@ -871,9 +871,10 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
 #endif
     if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
         (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > v2_num_cus()) {
-        if (epi == EPI_F16) return launch_v2_pers<EPI_F16>(p, s);
-        if (epi == EPI_GELU_F16) return launch_v2_pers<EPI_GELU_F16>(p, s);
-        if (epi == EPI_RESID_LS) return launch_v2_pers<EPI_RESID_LS>(p, s);
+        // (a device that does not grant all 160 KiB of LDS to one workgroup falls through to the one-tile-per-workgroup launch)
+        if (epi == EPI_F16 && launch_v2_pers<EPI_F16>(p, s) == 0) return 0;
+        if (epi == EPI_GELU_F16 && launch_v2_pers<EPI_GELU_F16>(p, s) == 0) return 0;
+        if (epi == EPI_RESID_LS && launch_v2_pers<EPI_RESID_LS>(p, s) == 0) return 0;
     }
     if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
     if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
