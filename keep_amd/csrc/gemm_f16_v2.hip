@@ -264,17 +264,18 @@ void gemm_f16_v2_kernel(GemmParams p) {
     };
     // MFMA group split in a head (first row of tiles) and a tail, so that the LDS reads / DMA issue
     // for the NEXT group can be pinned between them: they then never sit in front of a wait.
+    // HM MFMAs of a group before its memory instructions, the rest after.  Swept twice (before and after the K-loop clean-up) on the 8-MFMA
+    // groups of the 256x256 tile: 0 / 1 / 2 / 3 / 4 / 5 / 6 / 7 / 8 -> -4.1 / -1.6 / -1.4 / -0.6 / 0 / +0.3 / 0 / -0.6 / -1.4 % end to end.
+    constexpr int HM = (TN * TM == 8) ? 5 : TM;
     auto mfma_head = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[0], fa[j], acc[0][j], 0, 0, 0);
+        for (int m = 0; m < HM; ++m)
+            acc[m / TM][m % TM] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[m / TM], fa[m % TM], acc[m / TM][m % TM], 0, 0, 0);
     };
     auto mfma_tail = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) {
 #pragma unroll
-        for (int i = 1; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int m = HM; m < TN * TM; ++m)
+            acc[m / TM][m % TM] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[m / TM], fa[m % TM], acc[m / TM][m % TM], 0, 0, 0);
     };
     auto mfma_group = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) { mfma_head(fw, fa); mfma_tail(fw, fa); };
     // phase-2 (MX-fp4 correction terms, COMP only) operand stream; defined here because its first chunks are issued from the fp16 loop
