@@ -84,7 +84,7 @@ void layernorm_blk_kernel(LnParams p) {
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            v[i] = *reinterpret_cast<const f32x4*>(x + (i * 64 + lane) * 4);
+            v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (i * 64 + lane) * 4));     // streamed once (+0.25 %; the fp16 stores below measured better WITHOUT the hint)
             if (p.add) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(p.add + (int64_t)rc * p.x_stride + (i * 64 + lane) * 4);
 #pragma unroll
