@@ -1,4 +1,4 @@
-// fp16 MFMA GEMM, large-tile variant: 256 x BN x 64 tiles, 8 wavefronts, direct global->LDS DMA.
+// fp16 MFMA GEMM, large-tile variant: 256 x BN tiles, K step 32, 8 wavefronts, direct global->LDS DMA.
 //
 //   C[m][n] = sum_k A[m][k] * W[n][k]   (same contract and epilogues as gemm_f16.hip)
 //
@@ -16,6 +16,11 @@
 //     s_waitcnt vmcnt(G*(NSTAGE-2)) followed by a raw s_barrier (a __syncthreads() would drain the
 //     DMA queue to zero), and the DMA for tile s+NSTAGE-1 is issued right after that barrier
 //   * nseg == 3: hi/lo split product through the same accumulators (strict precision)
+//   * COMP: after the fp16 pass, the two first-order correction terms on the MX-fp4 pipe through the same accumulators (phase 2)
+//   * PERS: one workgroup per CU walks the tile sequence; the next tile's first three K steps are staged from the tail of the K loop
+//   * the K loop is written for its ISA: no branch but the back-edge, operand pointers carried from step to step, DMA addresses held in the
+//     scalar-base + 32-bit-lane-offset form (empty asm on the offsets), loops aligned to 64 B by the build -- every one of these was measured
+//     (DESIGN.md section 4); tests/test_build_artifacts.py checks that no kernel of the library spills
 #include "gemm_epilogue.h"
 #include "quant4.h"
 
@@ -515,7 +520,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // ---- phase 2: the two correction terms  W_lo A_hi^T + W_hi A_lo^T  on the MX-fp4 pipe (quant4.h) ------------------
     // Same accumulators, same wave tiling; K advances 64 per step (one v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile
     // and term: 32 cycles per SIMD against 4 x 32 for the fp16 pass over the same K).  Per step a workgroup streams
-    // 34 KiB (fp16 pass: 64 KiB per K = 64) through its own 4-stage LDS-DMA ring: 3 chunks in flight, counted vmcnt,
+    // 34 KiB (fp16 pass: 64 KiB per K = 64) through a 4-stage LDS-DMA ring laid over the fp16 ring's stages: 3 chunks in flight, counted vmcnt,
     // one raw barrier per chunk.
     if constexpr (COMP) {
         static_assert(BN == 256 && WM == 2 && WN == 4, "phase 2 is written for the 2 x 4 wave grid of the 256 x 256 tile");
