@@ -67,7 +67,8 @@ constexpr int V2_SC2 = 2048;
 constexpr int V2_NST2 = 4;
 constexpr int V2_SC2_BASE = V2_NST2 * V2_ST2;
 constexpr int V2_G2 = 5;             // phase-2 DMA instructions per wave per chunk
-constexpr int V2_PERS_LDS = 160 * 1024;   // persistent kernel: 3 prefetched stages (96 KiB) + 8 epilogue slabs of 8 KiB: all of the CU's LDS
+constexpr int V2_PERS_LDS = 160 * 1024;   // persistent kernel, fp32 epilogue: 3 prefetched stages (96 KiB) + 8 epilogue slabs of 8 KiB: all of the CU's LDS
+constexpr int V2_PERS_LDS_F16 = 96 * 1024 + 8 * 4608;   // fp16 epilogues: one padded fp16 plane per wave (132 KiB: a LayerNorm workgroup of the other lane still fits on the CU)
 
 // WD ("W direct", -DKEEP_EXPERIMENTS builds only): the W fragments come straight from global memory into registers
 // (fragment-ordered plane, common.h frag_off) and only A goes through the LDS ring: half of the LDS-DMA writes and a third of the
@@ -645,7 +646,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // That is exactly 32 x 64 fp32 without padding -- the 16-byte chunks of row r are rotated by r instead (same bank pattern as the padded
     // rows) -- and one fp16 plane with padding: the persistent kernel is launched for hi-only outputs.
     constexpr int SLAB_BASE = PERS ? 3 * (V2_BM + BN) * V2_BK * 2 : 0;
-    constexpr int SLAB_STRIDE = PERS ? 2048 : SLAB_FLOATS;                // floats per wave
+    constexpr int SLAB_STRIDE = PERS ? ((EPI == EPI_F16 || EPI == EPI_GELU_F16) ? 1152 : 2048) : SLAB_FLOATS;     // floats per wave
     static_assert(!PERS || (SLAB_BASE + SLAB_STRIDE * 4 * WM * WN <= V2_PERS_LDS && 32 * PITCH16 * 2 <= SLAB_STRIDE * 4), "persistent epilogue slabs must fit behind the three prefetched stages");
     float* slab = reinterpret_cast<float*>(smem_raw + SLAB_BASE) + wave * SLAB_STRIDE;
     auto slab_off = [&](int r, int col) { return PERS ? r * 64 + ((((col >> 2) + r) & 15) << 2) : r * PITCH + col; };   // col: multiple of 4
@@ -812,11 +813,12 @@ static int v2_num_cus() {
 template <int EPI>
 int launch_v2_pers(const GemmParams& p, hipStream_t s) {
     auto kernel = &gemm_f16_v2_kernel<256, 2, 4, 4, EPI, false, false, true>;
-    if (!v2_opt_in_lds(kernel, (size_t)V2_PERS_LDS)) return -2;
+    constexpr size_t lds_bytes = (EPI == EPI_F16 || EPI == EPI_GELU_F16) ? V2_PERS_LDS_F16 : V2_PERS_LDS;
+    if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
     const int tiles = (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM);
     int cus = v2_num_cus();
     if (p.tune && p.tune->gemm_persistent > 1 && p.tune->gemm_persistent < cus) cus = p.tune->gemm_persistent;     // experiment: fewer workgroups than CUs
-    hipLaunchKernelGGL(kernel, dim3(tiles < cus ? tiles : cus), dim3(512), (size_t)V2_PERS_LDS, s, p);
+    hipLaunchKernelGGL(kernel, dim3(tiles < cus ? tiles : cus), dim3(512), lds_bytes, s, p);
     return 0;
 }
 
