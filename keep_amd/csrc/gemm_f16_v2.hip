@@ -706,7 +706,8 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     f32x2 a = {acc[i][j][rg * 4 + 0] + bfrag[i * 4 + rg][0], acc[i][j][rg * 4 + 1] + bfrag[i * 4 + rg][1]};
                     f32x2 b = {acc[i][j][rg * 4 + 2] + bfrag[i * 4 + rg][2], acc[i][j][rg * 4 + 3] + bfrag[i * 4 + rg][3]};
                     if (EPI == EPI_GELU_F16) {
-                        if (p.out_lo || p.out_q) { a = gelu_fast2(a); b = gelu_fast2(b); }  // strict / compensated: full-accuracy polynomial
+                        // strict / compensated (lo or fp4 planes wanted): full-accuracy polynomial; a persistent launch is hi-only by construction
+                        if (!PERS && (p.out_lo || p.out_q)) { a = gelu_fast2(a); b = gelu_fast2(b); }
                         else { a = gelu_fast2_fp16(a); b = gelu_fast2_fp16(b); }
                     }
                     f16x4 h, l;
