@@ -707,7 +707,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     f32x2 b = {acc[i][j][rg * 4 + 2] + bfrag[i * 4 + rg][2], acc[i][j][rg * 4 + 3] + bfrag[i * 4 + rg][3]};
                     if (EPI == EPI_GELU_F16) {
                         // strict / compensated (lo or fp4 planes wanted): full-accuracy polynomial; a persistent launch is hi-only by construction
-                        if (!PERS && (p.out_lo || p.out_q)) { a = gelu_fast2(a); b = gelu_fast2(b); }
+                        if (COMP || (!PERS && (p.out_lo || p.out_q))) { a = gelu_fast2(a); b = gelu_fast2(b); }     // (a compensated launch always is)
                         else { a = gelu_fast2_fp16(a); b = gelu_fast2_fp16(b); }
                     }
                     f16x4 h, l;
