@@ -695,6 +695,12 @@ void gemm_f16_v2_kernel(GemmParams p) {
         }
     };
     if (!F16_OUT) load_res(0, res2[0], oo2[0]);
+    // fp16 outputs go to the blk layout (the consumer is a GEMM) or row-major (attention): ONE address form, offset(m) = (m / 256) * out_sa +
+    // (m % 256) * out_sb + out_g, with the three constants picked here -- a "which layout" test per store was two scalar branches in front of each
+    // of a tile's 16 stores
+    const int64_t out_sa = p.out_kt > 0 ? (int64_t)p.out_kt * 8192 : (int64_t)256 * p.N;
+    const int out_sb = p.out_kt > 0 ? 32 : p.N;
+    const int out_g = p.out_kt > 0 ? ((ncol >> 5) * 8192 + (ncol & 31)) : ncol;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int mbase = m0 + wm * (TM * 32) + j * 32;
@@ -726,7 +732,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                 const int m = mbase + r;
                 const f16x8 h = *reinterpret_cast<const f16x8*>(slab_hi + r * PITCH16 + ocol);
                 if (m < p.M) {
-                    const int64_t o = p.out_kt > 0 ? blk_off(m, ncol, p.out_kt) : (int64_t)m * p.N + ncol;
+                    const int64_t o = (int64_t)(m >> 8) * out_sa + (m & 255) * out_sb + out_g;
                     __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(p.out_hi + o));      // written once, read by the next kernel: +0.75 % non-temporal
                     if (want_lo) {
                         const f16x8 l = *reinterpret_cast<const f16x8*>(slab_lo + r * PITCH16 + ocol);
