@@ -162,6 +162,9 @@ void attention_kernel(AttnParams p) {
             if (SPLIT) qln[ks] = *reinterpret_cast<const f16x8*>(base_lo + (qo + ks * 32));
         }
     };
+    const bool o_blk = p.out_kt > 0;
+    const unsigned o_sa = o_blk ? (unsigned)p.out_kt * 8192u : 256u * (unsigned)D, o_sb = o_blk ? 32u : (unsigned)D;
+    const unsigned o_ga = o_blk ? 8192u : 32u, o_g0 = (o_blk ? (unsigned)(h * 2) * 8192u : (unsigned)(h * HD)) + (unsigned)(g * 4);
     if (wave < nqt) load_q(wave);
     asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));          // same as at the bottom of the loop: no pending Q load reaches the loop header on any path
     if (SPLIT) asm volatile("" : "+v"(qln[0]), "+v"(qln[1]));
@@ -301,9 +304,9 @@ void attention_kernel(AttnParams p) {
                 f16x4 oh, ol;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f16 hh, ll; split_f16(o[dt][r] * inv, hh, ll); oh[r] = hh; ol[r] = ll; }
-                const int col = h * HD + dt * 16 + g * 4;
-                const unsigned oo = p.out_kt > 0 ? ((unsigned)(mrow >> 8) * (unsigned)p.out_kt + (unsigned)(col >> 5)) * 8192u + (unsigned)(((mrow & 255) << 5) + (col & 31))
-                                                 : (unsigned)mrow * (unsigned)D + (unsigned)col;       // blk_off (common.h) in 32 bits
+                // blk layout (common.h blk_off, in 32 bits) or row-major, as ONE form: (m / 256) * o_sa + (m % 256) * o_sb + o_g0 + (dt / 2) * o_ga + (dt % 2) * 16,
+                // constants picked before the loop (a per-store "which layout" test is a pair of scalar branches)
+                const unsigned oo = (unsigned)(mrow >> 8) * o_sa + (unsigned)(mrow & 255) * o_sb + o_g0 + (unsigned)(dt >> 1) * o_ga + (unsigned)(dt & 1) * 16u;
                 *reinterpret_cast<f16x4*>(p.out_hi + oo) = oh;
                 if (SPLIT) *reinterpret_cast<f16x4*>(p.out_lo + oo) = ol;
             }
