@@ -99,8 +99,7 @@ int keep_bert_layers(keep_handle* h);
  *                     back onto the caller's stream with events (no host synchronisation)
  *   "cls_tail"        1 (default): in the last ViT block run proj / MLP for the CLS rows only (exact: the
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
- *   "gemm_impl"       0 auto | 128 | 256: LDS-DMA tile width override (-DKEEP_EXPERIMENTS builds also accept the
- *                     measured-negative variants 1, 3, 2128, 3256, 4256).  Like every option it belongs to the handle.
+ *   "gemm_impl"       0 auto | 128 | 256: LDS-DMA tile width override.  Like every option it belongs to the handle.
  *   "graphs"          1 (default): calls of at most 1024 rows (a few prompts / tiles: ~100 dependent kernels of a few
  *                     microseconds) are captured once and replayed as one hipGraph launch; 0: always launch kernels
  *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 320, 0 never).  The two GEMM paths agree to rounding, each is bit-reproducible

@@ -19,7 +19,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkeep_hip.so")
 SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
-EXPERIMENT_SOURCES = ["gemm_f16_v3.hip"]      # compiled only with KEEP_BUILD_DEFINES=-DKEEP_EXPERIMENTS (measured-negative variants)
 # -falign-loops=64: the hot loops start on an instruction-cache line.  Without it a functionally identical edit elsewhere in a kernel moved the
 # K loop of the GEMM by a few dwords and the whole encoder by up to 3 % (measured: DESIGN.md section 4); with it +0.5 % and reproducible.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-falign-loops=64", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value",
@@ -46,7 +45,7 @@ def _sha(paths, extra="") -> str:
 
 
 def _sources(defines):
-    return SOURCES + (EXPERIMENT_SOURCES if "-DKEEP_EXPERIMENTS" in defines else [])
+    return list(SOURCES)
 
 
 def _source_keys(defines):

@@ -55,12 +55,6 @@ __device__ __forceinline__ float wave_max(float v) {
 __host__ __device__ __forceinline__ int64_t blk_off(int m, int k, int KT) {
     return ((int64_t)(m >> 8) * KT + (k >> 5)) * 8192 + ((m & 255) << 5) + (k & 31);
 }
-// Fragment-ordered weight plane ("frag"): W[n][k] for the register-direct W path of the 256x256 GEMM.  One 32(n) x 32(k) tile is two
-// 1 KiB groups (ks = 0, 1); inside a group lane (fhi * 32 + n % 32) owns the 8 consecutive k  kt*32 + ks*16 + fhi*8 ..+7 -- exactly the
-// 32x32x16 MFMA operand of that lane, so a wave's fragment load is ONE fully contiguous global_load_dwordx4.
-__host__ __device__ __forceinline__ int64_t frag_off(int n, int k, int KT) {
-    return ((((int64_t)(n >> 5) * KT + (k >> 5)) * 2 + ((k >> 4) & 1)) * 64 + (((k >> 3) & 1) << 5) + (n & 31)) * 8 + (k & 7);
-}
 static inline size_t blk_elems(int64_t M, int64_t K) { return (size_t)((M + 255) / 256 * 256) * (size_t)K; }
 
 // ---------------------------------------------------------------------------
@@ -70,9 +64,8 @@ static inline size_t blk_elems(int64_t M, int64_t K) { return (size_t)((M + 255)
 // Kernel-selection knobs.  They belong to a handle (keep_set_option) and travel inside the launch parameter blocks:
 // there is no process-wide kernel state, so two handles (two GPUs, two threads) never see each other's settings.
 struct KeepTune {
-    int gemm_impl = 0;           // 0 auto | 128 / 256: LDS-DMA tile width (experiment builds add more)
+    int gemm_impl = 0;           // 0 auto | 128 / 256: LDS-DMA tile width 
     int gemm_skinny_m = 320;     // calls with M <= this take the register-direct split-K kernel (0: never)
-    int w_direct = 0;            // experiment builds: 256x256 GEMM with W fragments global -> registers (needs the frag plane); measured neutral
     int gemm_splitk_tiles = 64;  // a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never)
     int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
     int ln_impl = 1;             // 1: LDS-transposed blk stores; 0: per-row stores
@@ -101,8 +94,6 @@ enum GemmEpi : int {
 struct GemmParams {
     const f16* a_hi; const f16* a_lo;     // activations [M][K] in blk layout (row-major for the v1 kernel); lo only when nseg==3
     const f16* w_hi; const f16* w_lo;     // weights [N][K], same layout as A
-    const f16* w_frag;                    // optional: w_hi in MFMA-fragment order (frag_off below): the 256x256 kernel then loads its W
-                                          // fragments straight from global memory into registers and only A goes through LDS
     int M, N, K;                          // K = per-segment depth; multiples: N%128==0, K%64==0
     int nseg;                             // 1: A_hi*W_hi ; 3: A_hi*W_hi + A_lo*W_hi + A_hi*W_lo
     // comp != 0: after the fp16 pass the two correction terms run on the MX-fp4 pipe (quant4.h): needs the fp4 side planes
@@ -133,7 +124,6 @@ struct GemmParams {
 
 int launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);             // blk-layout operands (product path); returns GEMM_DID_LN or 0
 constexpr int GEMM_DID_LN = 1;
-void launch_gemm_f16_rowmajor(const GemmParams& p, int epi, hipStream_t s);   // row-major operands (test cross-check)
 // split-K scratch: 30 MiB cover every small-M shape (M <= SKINNY_MAX_M: <= 768 + 1024 partial tiles of 32 x 128 fp32);
 // the mid-size path (256x256 tiles x K slices when a GEMM has fewer tiles than CUs) needs <= 448 tiles of 256 KiB
 constexpr int SKINNY_MAX_M = 1024;
@@ -192,8 +182,6 @@ void launch_resize_crop_u8(const unsigned char* src, int B, int H, int W, const 
 void launch_split_f16(const float* src, f16* hi, f16* lo, int64_t n, hipStream_t s);
 // row-major fp32 [M][K] -> blk-layout fp16 hi (+lo); rows M..pad are zero-filled
 void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hipStream_t s);
-// fp32 [N][K] -> fp16 in fragment order (frag_off); N % 32 == 0, K % 32 == 0
-void launch_fragify(const float* src, f16* frag, int N, int K, hipStream_t s);
 // the same plus the MX-fp4 side planes of quant4.h (q: both planes, sc: scales); K % 32 == 0; lo may be null
 void launch_quant_blockify(const float* src, f16* hi, f16* lo, unsigned char* q, unsigned char* sc, int M, int K, hipStream_t s);
 // blk-layout fp16 hi (+lo) -> row-major fp32 [M][K]

@@ -41,7 +41,6 @@ struct WTensor {
     float* f32 = nullptr;     // kept for vectors / embeddings / head / pooler
     f16* hi = nullptr;        // GEMM weights: fp16 planes
     f16* lo = nullptr;
-    f16* frag = nullptr;      // hi plane in MFMA-fragment order (common.h frag_off): W-direct path of the 256x256 GEMM
     unsigned char* q = nullptr;   // MX-fp4 side planes of (hi, lo) and their scales (quant4.h); K % 128 == 0 weights only
     unsigned char* sc = nullptr;
 };
@@ -339,7 +338,7 @@ void offer_ln(GemmParams& p, const LnParams& ln) {
 GemmParams gemm_params(const keep_handle* h, const f16* a_hi, const f16* a_lo, const WTensor* w, int M, bool split, const float* bias) {
     GemmParams p{};
     p.tune = &h->tune;
-    p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w->hi; p.w_lo = w->lo; p.w_frag = w->frag;
+    p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w->hi; p.w_lo = w->lo;
     p.M = M; p.N = (int)w->shape[0]; p.K = (int)(w->numel / w->shape[0]);
     p.nseg = split ? 3 : 1;
     p.bias = bias;
@@ -616,12 +615,6 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         } else {
             launch_split_blockify(dev, t.hi, t.lo, (int)n, (int)k, nullptr);
         }
-#ifdef KEEP_EXPERIMENTS
-        if (h->tune.w_direct && starts_with(key, "visual.blocks.") && (k / 32) % 2 == 0 && k / 32 >= 4) {     // W-direct experiment: fragment-ordered copy (option set before loading)
-            HIPCHK(h, hipMalloc(&t.frag, t.numel * sizeof(f16)));
-            launch_fragify(dev, t.frag, (int)n, (int)k, nullptr);
-        }
-#endif
         HIPCHK(h, hipStreamSynchronize(nullptr));
     } else {
         const size_t bytes = (size_t)(t.numel > 4 ? t.numel : 4) * sizeof(float);
@@ -635,7 +628,6 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         if (it->second.lo) hipFree(it->second.lo);
         if (it->second.q) hipFree(it->second.q);
         if (it->second.sc) hipFree(it->second.sc);
-        if (it->second.frag) hipFree(it->second.frag);
     }
     h->w[key] = t;
     h->finalized = false;
@@ -847,7 +839,7 @@ int keep_destroy(keep_handle* h) {
     h->prof_collect();
     for (auto& e : h->pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo);
-                            if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); if (kv.second.frag) hipFree(kv.second.frag); }
+                            if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); }
     if (h->tune.dbg) hipFree(h->tune.dbg);
     for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
     drop_graphs(h);
@@ -920,9 +912,6 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
-#ifdef KEEP_EXPERIMENTS
-    else if (n == "w_direct") { t.w_direct = v ? 1 : 0; }
-#endif
     else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
     else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
     else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); t.sgemv_m = v; }
@@ -934,10 +923,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); t.attn_waves = v; }
     else if (n == "gemm_impl") {
         bool ok = v == 0 || v == 128 || v == 256;
-#ifdef KEEP_EXPERIMENTS
-        ok = ok || v == 1 || v == 3 || v == 2128 || v == 3256 || v == 4256 || v == 5256;
-#endif
-        if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256; experiment builds add 1, 3, 2128, 3256, 4256)", v);
+        if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256)", v);
         t.gemm_impl = v;
     }
 #ifdef KEEP_DIAGNOSTICS
@@ -966,7 +952,6 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "gemm_impl") return t.gemm_impl;
     if (n == "streams") return h->n_streams;
     if (n == "graphs") return h->use_graphs;
-    if (n == "w_direct") return t.w_direct;
     if (n == "gemm_skinny_m") return t.gemm_skinny_m;
     if (n == "sgemv_m") return t.sgemv_m;
     if (n == "gemm_splitk_tiles") return t.gemm_splitk_tiles;
@@ -1388,8 +1373,7 @@ int keep_profile_reset(keep_handle* h) {
 int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls, const float* resid,
                    int64_t M, int64_t N, int64_t K, int epi, int split, float* out, void* stream) {
     if (!h || !a || !w || !bias || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
-    const bool rowmajor = (h->tune.gemm_impl == 1);      // cross-check variant: 128x128 register-staged kernel on row-major operands
-    if (M < 1 || N % 128 || N < 128 || K < 64 || K % (rowmajor ? 64 : 32)) return h->fail(KEEP_EUNSUPPORTED, "linear needs N%%128==0 and K%%32==0 (K%%64 for gemm_impl=1)");
+    if (M < 1 || N % 128 || N < 128 || K < 64 || K % 32) return h->fail(KEEP_EUNSUPPORTED, "linear needs N%%128==0 and K%%32==0");
     if (epi != EPI_F16 && epi != EPI_GELU_F16 && epi != EPI_RESID_LS && epi != EPI_RESID_F32) return h->fail(KEEP_EINVAL, "epilogue %d", epi);
     if ((epi == EPI_RESID_LS && (!ls || !resid)) || (epi == EPI_RESID_F32 && !resid)) return h->fail(KEEP_EINVAL, "missing ls/resid");
     KEEP_ON_DEVICE(h);
@@ -1403,35 +1387,26 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     const bool comp = split == 2;
     unsigned char *a_q = nullptr, *a_sc = nullptr, *w_q = nullptr, *w_sc = nullptr;
     if (comp) {
-        if (rowmajor || N % 256 || K % 128 || K < 256 || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%128==0, K>=256 and epilogue 0/1/2");
+        if (N % 256 || K % 128 || K < 256 || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%128==0, K>=256 and epilogue 0/1/2");
         a_q = t.get<unsigned char>(keepk::q4_data_bytes(M, K)); a_sc = t.get<unsigned char>(keepk::q4_scale_bytes(M, K));
         w_q = t.get<unsigned char>(keepk::q4_data_bytes(N, K)); w_sc = t.get<unsigned char>(keepk::q4_scale_bytes(N, K));
         if (!a_q || !a_sc || !w_q || !w_sc) return h->fail(KEEP_ENOMEM, "temp alloc");
         launch_quant_blockify(a, a_hi, a_lo, a_q, a_sc, (int)M, (int)K, s); launch_quant_blockify(w, w_hi, w_lo, w_q, w_sc, (int)N, (int)K, s);
     }
-    else if (rowmajor) { launch_split_f16(a, a_hi, a_lo, M * K, s); launch_split_f16(w, w_hi, w_lo, N * K, s); }
     else { launch_split_blockify(a, a_hi, a_lo, (int)M, (int)K, s); launch_split_blockify(w, w_hi, w_lo, (int)N, (int)K, s); }
     GemmParams p{};
     p.tune = &h->tune;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.nseg = (split == 1) ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
-    if (!rowmajor && N % 32 == 0 && h->tune.w_direct) {              // W-direct experiment: a fragment-ordered copy of the weight
-        f16* w_frag = t.get<f16>(N * K);
-        if (!w_frag) return h->fail(KEEP_ENOMEM, "temp alloc");
-        launch_fragify(w, w_frag, (int)N, (int)K, s);
-        p.w_frag = w_frag;
-    }
     if (comp) { p.comp = 1; p.a_q = a_q; p.a_sc = a_sc; p.w_q = w_q; p.w_sc = w_sc; }
-    if (!rowmajor) {                               // auto mode may take a split-K path (small or mid-size M), as the towers do
-        p.splitk_ws = t.get<float>(SKINNY_WS_BYTES / 4); p.splitk_bytes = SKINNY_WS_BYTES;
-        if (!p.splitk_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
-    }
+    p.splitk_ws = t.get<float>(SKINNY_WS_BYTES / 4); p.splitk_bytes = SKINNY_WS_BYTES;      // auto mode may take a split-K path (small or mid-size M), as the towers do
+    if (!p.splitk_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
     int launch_rc = 0;
-    auto launch = [&](const GemmParams& q) { if (rowmajor) launch_gemm_f16_rowmajor(q, epi, s); else launch_rc = launch_gemm_f16(q, epi, s); };
+    auto launch = [&](const GemmParams& q) { launch_rc = launch_gemm_f16(q, epi, s); };
     if (epi == EPI_F16 || epi == EPI_GELU_F16) {
         p.out_hi = o_hi; p.out_lo = split ? o_lo : nullptr;
         // as in the towers: the GELU output feeds another GEMM (blk layout), the plain one feeds attention (row-major)
-        p.out_kt = (!rowmajor && epi == EPI_GELU_F16) ? (int)(N / 32) : 0;
+        p.out_kt = (epi == EPI_GELU_F16) ? (int)(N / 32) : 0;
         launch(p);
         if (p.out_kt) launch_unblockify_f32(o_hi, split ? o_lo : nullptr, out, (int)M, (int)N, s);
         else planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * N, s);
@@ -1466,13 +1441,6 @@ int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* 
     if (!w1h || !w1l || !w2h || !w2l || !xh || !xl || !mh || !ml || !w1q || !w1s || !w2q || !w2s || !xq || !xs || !mq || !ms || !ws) return h->fail(KEEP_ENOMEM, "temp alloc");
     launch_quant_blockify(fc1_w, w1h, w1l, w1q, w1s, (int)F, (int)D, s);
     launch_quant_blockify(fc2_w, w2h, w2l, w2q, w2s, (int)D, (int)F, s);
-    f16 *w1f = nullptr, *w2f = nullptr;
-    if (h->tune.w_direct) {
-        w1f = t.get<f16>(F * D); w2f = t.get<f16>(D * F);
-        if (!w1f || !w2f) return h->fail(KEEP_ENOMEM, "temp alloc");
-        launch_fragify(fc1_w, w1f, (int)F, (int)D, s);
-        launch_fragify(fc2_w, w2f, (int)D, (int)F, s);
-    }
     HIPCHK(h, hipMemcpyAsync(out, x, M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     LnParams ln{};
     ln.tune = &h->tune;
@@ -1481,14 +1449,12 @@ int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* 
     if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: layernorm");
     GemmParams p{};
     p.tune = &h->tune; p.patches_per_img = 196; p.splitk_ws = ws; p.splitk_bytes = SKINNY_WS_BYTES;
-    p.w_frag = w1f;
     p.a_hi = xh; p.a_lo = xl; p.w_hi = w1h; p.w_lo = w1l; p.M = (int)M; p.N = (int)F; p.K = (int)D; p.nseg = lo ? 3 : 1; p.bias = fc1_b;
     p.out_hi = mh; p.out_lo = lo ? ml : nullptr; p.out_kt = (int)(F / 32);
     if (q) { p.comp = 1; p.a_q = xq; p.a_sc = xs; p.w_q = w1q; p.w_sc = w1s; p.out_q = mq; p.out_sc = ms; }
     if (launch_gemm_f16(p, EPI_GELU_F16, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: fc1");
     GemmParams r{};
     r.tune = &h->tune; r.patches_per_img = 196; r.splitk_ws = ws; r.splitk_bytes = SKINNY_WS_BYTES;
-    r.w_frag = w2f;
     r.a_hi = mh; r.a_lo = ml; r.w_hi = w2h; r.w_lo = w2l; r.M = (int)M; r.N = (int)D; r.K = (int)F; r.nseg = lo ? 3 : 1; r.bias = fc2_b;
     r.ls = ls; r.resid = out;
     if (q) { r.comp = 1; r.a_q = mq; r.a_sc = ms; r.w_q = w2q; r.w_sc = w2s; }

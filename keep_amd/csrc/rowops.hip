@@ -269,17 +269,6 @@ __global__ void quant_blockify_kernel(const float* __restrict__ src, f16* __rest
         q4_store8(q, sc, KT, m, k >> 5, (k >> 3) & 3, h, l);
     }
 }
-__global__ void fragify_kernel(const float* __restrict__ src, f16* __restrict__ frag, int N, int K) {
-    const int KT = K / 32;
-    const int64_t total = (int64_t)N * (K / 8);
-    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(it / (K / 8)), k = (int)(it % (K / 8)) * 8;
-        f16x8 h;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = to_f16_sat(src[(int64_t)n * K + k + e]);
-        *reinterpret_cast<f16x8*>(frag + frag_off(n, k, KT)) = h;
-    }
-}
 __global__ void unblockify_f32_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo, float* __restrict__ out, int M, int K) {
     const int KT = K / 32;
     const int64_t total = (int64_t)M * K;
@@ -557,11 +546,6 @@ void launch_quant_blockify(const float* src, f16* hi, f16* lo, unsigned char* q,
     const int64_t total = (int64_t)((M + 255) / 256 * 256) * (K / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(quant_blockify_kernel, dim3(blocks), dim3(256), 0, s, src, hi, lo, q, sc, M, K);
-}
-void launch_fragify(const float* src, f16* frag, int N, int K, hipStream_t s) {
-    const int64_t total = (int64_t)N * (K / 8);
-    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fragify_kernel, dim3(blocks), dim3(256), 0, s, src, frag, N, K);
 }
 void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s) {
     const int64_t total = (int64_t)M * K;

@@ -29,8 +29,7 @@ GEMM_SHAPES = [(394, 3072, 1024), (128, 128, 64), (200, 768, 768), (77, 1024, 40
 
 @pytest.fixture(params=[128, 256, 0], ids=["v2_256x128", "v2_256x256", "auto_splitk"])
 def gemm_impl(ops, request):
-    """Run the GEMM tests once per kernel variant of the product build (256-wide falls back to 128-wide for N % 256 != 0; the
-    measured-negative variants only exist in -DKEEP_EXPERIMENTS builds).  0 = the product's automatic choice, with the
+    """Run the GEMM tests once per kernel variant of the product build (256-wide falls back to 128-wide for N % 256 != 0).  0 = the product's automatic choice, with the
     small-M split-K kernel taking every shape up to its 1024-row limit."""
     ops.set_option("gemm_impl", request.param)
     skinny = 320
@@ -197,37 +196,6 @@ def test_persistent_gemm_is_bit_identical_to_one_tile_per_workgroup(M, N, K, epi
     elif epi == EPI_GELU_F16:
         ref = gelu64(ref)
     assert (outs[1].double() - ref).abs().max().item() < 0.05
-
-
-@pytest.mark.parametrize("M,N,K,epi,split", [(394, 3072, 1024, EPI_F16, 0), (1182, 4096, 1024, EPI_GELU_F16, 0), (2048, 1024, 4096, EPI_RESID_LS, 0),
-                                             (700, 1024, 1024, EPI_RESID_LS, 0), (1000, 256, 192, EPI_F16, 0), (512, 768, 3072, EPI_RESID_LS, 2),
-                                             (1576, 4096, 1024, EPI_GELU_F16, 2), (300, 256, 128, EPI_F16, 0)])
-def test_w_direct_path_is_bit_identical_to_the_lds_path(ops, M, N, K, epi, split):
-    """The 256x256 GEMM with its W fragments loaded straight into registers (fragment-ordered weight plane, hand-counted vmcnt
-    across LDS-DMA and register loads) feeds the MFMAs the same operands in the same order as the both-operands-through-LDS
-    loop: the outputs must agree bit for bit -- every K-step count incl. the shortest (4) and the peeled tail, ragged M."""
-    try:
-        ops.set_option("w_direct", 0)
-    except ValueError:
-        pytest.skip("W-direct is a measured-neutral experiment: only in -DKEEP_EXPERIMENTS builds")
-    a, w, b = rand(M, K, seed=51), rand(N, K, seed=52, std=0.04), rand(N, seed=53, std=0.1)
-    ls = torch.rand(N, generator=torch.Generator().manual_seed(54)) * 0.45 + 0.05
-    resid = rand(M, N, seed=55)
-    kw = dict(ls=ls, resid=resid) if epi == EPI_RESID_LS else {}
-    ops.set_option("gemm_impl", 256); ops.set_option("gemm_skinny_m", 0); ops.set_option("gemm_splitk_tiles", 0)
-    try:
-        ops.set_option("w_direct", 1)
-        direct = ops.linear(a, w, b, epi, split, **kw)
-        again = ops.linear(a, w, b, epi, split, **kw)
-        ops.set_option("w_direct", 0)
-        via_lds = ops.linear(a, w, b, epi, split, **kw)
-    finally:
-        ops.set_option("w_direct", 0); ops.set_option("gemm_impl", 0); ops.set_option("gemm_skinny_m", 320); ops.set_option("gemm_splitk_tiles", 64)
-    assert torch.equal(direct, again)
-    assert torch.equal(direct, via_lds)
-    ref = a.double() @ w.double().t() + b.double()
-    if epi == EPI_F16:
-        assert (direct.cpu().double() - ref).abs().max() < 5e-3 * max(1.0, ref.abs().max().item())
 
 
 def test_linear_is_not_transposed(ops, gemm_impl):

@@ -70,13 +70,18 @@ constexpr int V2_G2 = 5;             // phase-2 DMA instructions per wave per ch
 constexpr int V2_PERS_LDS = 160 * 1024;   // persistent kernel, fp32 epilogue: 3 prefetched stages (96 KiB) + 8 epilogue slabs of 8 KiB: all of the CU's LDS
 constexpr int V2_PERS_LDS_F16 = 96 * 1024 + 8 * 4608;   // fp16 epilogues: one padded fp16 plane per wave (132 KiB: a LayerNorm workgroup of the other lane still fits on the CU)
 
+// WD ("W direct", -DKEEP_EXPERIMENTS builds only): the W fragments come straight from global memory into registers
+// (fragment-ordered plane, common.h frag_off) and only A goes through the LDS ring: half of the LDS-DMA writes and a third of the
+// ds_read traffic of a K step gone.  Built because ablations that dropped W's LDS traffic ran 17-19 % faster -- which turned out to be
+// the zero / stale operands those ablations feed the MFMAs (the part is power-limited: low-entropy operands raise its clock).  With real
+// loads the variant is bit-identical and exactly as fast as the two-operand loop.  Kept as the record of that.
 // PERS ("persistent"): one workgroup per CU walks the tile sequence with stride gridDim.x and stages the first three K steps of its NEXT tile into the
 // ring stages that retire during the last steps of the current one, so they land while the epilogue runs (which then bounces through the
 // fourth stage and the 32 KiB of LDS behind the ring).  Same arithmetic, same tile order per XCD (tile t and t + 256 map to the same XCD).
-template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP = false, bool PERS = false>
+template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP = false, bool WD = false, bool PERS = false>
 __global__ __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BN, WM, WN))
 void gemm_f16_v2_kernel(GemmParams p) {
-    static_assert(!PERS || (BN == 256 && NSTAGE == 4 && !COMP && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_RESID_LS)),
+    static_assert(!PERS || (BN == 256 && NSTAGE == 4 && !COMP && !WD && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_RESID_LS)),
                   "the persistent walk is written for the plain 256x256 / 4-stage kernel");
     constexpr int V2_THREADS = WM * WN * 64;
     constexpr int BM = V2_BM, BK = V2_BK;
@@ -310,9 +315,104 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // PRE: chunks 0..2 of phase 2 go out from the last fp16 steps, each into the phase-1 stage that step has just retired (chunk c lands in
     // stage c: the launcher admits compensated products only with a step count that is a multiple of the ring depth, K % 128 == 0, and
     // K >= 256) -- the fp4 phase then starts with its ring already full.
-    constexpr bool PRE = COMP && NSTAGE == V2_NST2;
+    constexpr bool PRE = COMP && !WD && NSTAGE == V2_NST2;
 #define KEEP_PIN() __builtin_amdgcn_sched_barrier(0)
 
+  if constexpr (WD) {
+    // ---- W-direct main loop ------------------------------------------------------------------------------------------------
+    // LDS ring: A only (NSTAGE x 16 KiB).  W: per wave and K step 2 n-tiles x 2 k-halves = 4 fully contiguous 1 KiB loads, issued
+    // TWO steps ahead into the registers the MFMAs of the current step have just consumed (two register sets, the loop is unrolled by
+    // two so the sets alternate statically).  One VMEM counter serves both kinds of load and retires in order; per wave the issue
+    // sequence of a step s is   [after group 0] W0(s+2) x2   [after group 1] W1(s+2) x2, A-DMA(s+4) x2   and the waits are
+    //     top of step s (needs W0(s)):  younger = W1(s) 2 + A(s+2) 2 + W0(s+1) 2 + W1(s+1) 2 + A(s+3) 2          -> vmcnt(10)
+    //     before the barrier (needs W1(s), and A(s+1), which is older):  A(s+2) 2 + W(s+1) 4 + A(s+3) 2 + W0(s+2) 2 -> vmcnt(10)
+    // so an A-DMA stays in flight for 2+ steps, as in the two-operand loop.  The last three steps are peeled (counts 8/8, 6/4, 2/0).
+    // The loads are inline asm (hipcc would otherwise drain the DMA queue with vmcnt(0) at the first use of a register load); the
+    // wait statements name the destination registers so nothing is scheduled across them.
+    static_assert(BN == 256 && WM == 2 && WN == 4 && NSTAGE == 4, "W-direct loop is written for the 256x256 / 2x4 waves / 4-stage tile");
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int A_STAGE = BM * BK;                       // f16 elements
+    const int S = KT;                                      // steps (nseg == 1, no K split); even and >= 4 (checked by the launcher)
+    f16x8 fwa0[TN], fwa1[TN], fwb0[TN], fwb1[TN];          // W fragments: sets a (even steps) and b (odd steps), k-half 0 and 1
+    // per-wave base of this wave's first n-tile in the frag plane; tile i adds KT * 2 KiB, step kt adds 2 KiB, k-half 1 adds 1 KiB
+    const char* wbase = reinterpret_cast<const char*>(p.w_frag) + (int64_t)((n0 >> 5) + wn * TN) * KT * 2048;
+    const unsigned wlane = lane * 16;
+    auto stage_a = [&](int st, int buf) {
+        const f16* ab = p.a_hi + a_tile + (int64_t)st * 8192;
+        f16* sa = lds + buf * A_STAGE;
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r)
+            __builtin_amdgcn_global_load_lds((gptr_t)(ab + a_off[r]), (lptr_t)(sa + (r * V2_THREADS + wave * 64) * 8), 16, 0, KEEP_A_AUX);
+    };
+    auto read_fa = [&](int st, int ks, f16x8 (&fa)[TM]) {
+        const f16* sa = lds + st * A_STAGE;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            fa[j] = *reinterpret_cast<const f16x8*>(sa + v2_lds_off(wm * (TM * 32) + j * 32 + frow, ks * 2 + fhi, swz_mask));
+    };
+#define KEEP_LOADW(FW, ST, KS)                                                                                                     \
+    {                                                                                                                              \
+        const char* b0_ = wbase + (int64_t)(ST) * 2048 + (KS) * 1024;                                                              \
+        const char* b1_ = b0_ + (int64_t)KT * 2048;                                                                                \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(FW[0]) : "v"(wlane), "s"(b0_) : "memory");                             \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(FW[1]) : "v"(wlane), "s"(b1_) : "memory");                             \
+    }
+#define KEEP_WAITW(N, FW) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(FW[0]), "+v"(FW[1]) : : "memory")
+    // one K step on W set (FW0, FW1); LW / LA: whether W(s+2) / A(s+4) still exist
+#define KEEP_WSTEP(ST, FW0, FW1, VTOP, VMID, LW, LA)                                                                               \
+    {                                                                                                                              \
+        KEEP_WAITW(VTOP, FW0);                                                                                                     \
+        KEEP_PIN();                                                                                                                \
+        mfma_head(FW0, fa0);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        read_fa((ST) % NSTAGE, 1, fa1);                                                                                            \
+        KEEP_PIN();                                                                                                                \
+        mfma_tail(FW0, fa0);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        if (LW) KEEP_LOADW(FW0, (ST) + 2, 0)                                                                                       \
+        KEEP_WAITW(VMID, FW1);                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                                              \
+        KEEP_PIN();                                                                                                                \
+        mfma_head(FW1, fa1);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        read_fa(((ST) + 1) % NSTAGE, 0, fa0);                                                                                      \
+        KEEP_PIN();                                                                                                                \
+        mfma_tail(FW1, fa1);                                                                                                       \
+        KEEP_PIN();                                                                                                                \
+        if (LW) KEEP_LOADW(FW1, (ST) + 2, 1)                                                                                       \
+        if (LA) stage_a((ST) + 4, (ST) % NSTAGE);                                                                                  \
+    }
+    // prologue in the steady-state issue order: A(0) A(1) | W0(0) | W1(0) A(2) | W0(1) | W1(1) A(3)
+    stage_a(0, 0); stage_a(1, 1);
+    KEEP_LOADW(fwa0, 0, 0)
+    KEEP_LOADW(fwa1, 0, 1)
+    stage_a(2, 2);
+    KEEP_LOADW(fwb0, 1, 0)
+    KEEP_LOADW(fwb1, 1, 1)
+    stage_a(3, 3);
+    KEEP_WAITW(10, fwa0);                                  // W0(0) and everything older (A(0), A(1)) have landed
+    __builtin_amdgcn_s_barrier();
+    read_fa(0, 0, fa0);
+    int s = 0;
+    for (; s < S - 4; s += 2) {
+        KEEP_WSTEP(s, fwa0, fwa1, 10, 10, true, true)
+        KEEP_WSTEP(s + 1, fwb0, fwb1, 10, 10, true, true)
+    }
+    // s == S - 4 (even): steps S-4 .. S-1
+    KEEP_WSTEP(s, fwa0, fwa1, 10, 10, true, false)         // W(S-2) exists, A(S) does not
+    KEEP_WSTEP(s + 1, fwb0, fwb1, 8, 8, true, false)       // step S-3: W(S-1) exists
+    KEEP_WSTEP(s + 2, fwa0, fwa1, 6, 4, false, false)      // step S-2
+    KEEP_WSTEP(s + 3, fwb0, fwb1, 2, 0, false, false)      // step S-1
+#undef KEEP_WSTEP
+#undef KEEP_WAITW
+#undef KEEP_LOADW
+  } else {
 
     if (PERS && p.dbg && !first_tile) t_start = __builtin_readcyclecounter();      // diagnostics: the stamps describe the workgroup's LAST tile
     if (!PERS || first_tile) {
@@ -415,6 +515,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
     KEEP_PIN();
     mfma_tail(fw0, fa0);
     mfma_group(fw1, fa1);
+  }
 #undef KEEP_PIN
 
     // ---- phase 2: the two correction terms  W_lo A_hi^T + W_hi A_lo^T  on the MX-fp4 pipe (quant4.h) ------------------
@@ -718,7 +819,7 @@ static int v2_num_cus() {
 
 template <int EPI>
 int launch_v2_pers(const GemmParams& p, hipStream_t s) {
-    auto kernel = &gemm_f16_v2_kernel<256, 2, 4, 4, EPI, false, true>;
+    auto kernel = &gemm_f16_v2_kernel<256, 2, 4, 4, EPI, false, false, true>;
     constexpr size_t lds_bytes = (EPI == EPI_F16 || EPI == EPI_GELU_F16) ? V2_PERS_LDS_F16 : V2_PERS_LDS;
     if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
     const int tiles = (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM);
@@ -728,12 +829,12 @@ int launch_v2_pers(const GemmParams& p, hipStream_t s) {
     return 0;
 }
 
-template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP>
+template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP, bool WD = false>
 int launch_v2_one(const GemmParams& p, hipStream_t s) {
     constexpr size_t ring = (size_t)NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
     constexpr size_t ring2 = (size_t)V2_NST2 * (V2_ST2 + V2_SC2);
     constexpr size_t lds_bytes = COMP && ring2 > ring ? ring2 : ring;
-    auto kernel = &gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI, COMP>;
+    auto kernel = &gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI, COMP, WD>;
     if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
     const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM) * (EPI == EPI_PARTIAL ? p.ksplit : 1);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WM * WN * 64), lds_bytes, s, p);
@@ -761,8 +862,18 @@ int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
 int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s) {
     using namespace keepk;
     if (p.K % V2_BK) return 1;
+#ifdef KEEP_EXPERIMENTS
+    // W-direct variant (correct, bit-identical, measured NEUTRAL: 7 082 vs 7 073 tiles/s -- DESIGN.md section 4): needs the
+    // fragment-ordered weight plane, one fp16 pass, an even number (>= 4) of K steps
+    const bool wd = p.w_frag && p.tune && p.tune->w_direct && p.nseg == 1 && p.N % 256 == 0 && (p.K / V2_BK) % 2 == 0 && p.K / V2_BK >= 4 &&
+                    (variant == 256 || p.comp);
+#endif
     if (p.comp) {
         if (p.N % 256 || p.K % 128 || p.K < 256 || p.nseg != 1 || !p.a_q || !p.a_sc || !p.w_q || !p.w_sc) return 1;
+#ifdef KEEP_EXPERIMENTS
+        if (wd && epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, true, true>(p, s);
+        if (wd && epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, true, true>(p, s);
+#endif
         if (epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, true>(p, s);
         if (epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, true>(p, s);
         if (epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, true>(p, s);
@@ -770,6 +881,11 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
         return 1;
     }
     if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, false>(p, s);
+#ifdef KEEP_EXPERIMENTS
+    if (wd && epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, false, true>(p, s);
+    if (wd && epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, false, true>(p, s);
+    if (wd && epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, false, true>(p, s);
+#endif
     if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
         (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > v2_num_cus()) {
         // (a device that does not grant all 160 KiB of LDS to one workgroup falls through to the one-tile-per-workgroup launch)
@@ -779,5 +895,13 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
     }
     if (variant == 256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 4>(p, epi, s);
     if (variant == 128 && p.N % 128 == 0) return launch_v2<128, 4, 2, 4>(p, epi, s);
+#ifdef KEEP_EXPERIMENTS
+    // measured-negative variants, kept as the record of the experiments: 96 KiB ring; 4 waves x 128x128
+    // (11 % slower end to end: the LDS-DMA issue cost is exposed with one wave per SIMD); 256x128 / 4 waves / two workgroups per CU
+    if (variant == 3256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 3>(p, epi, s);
+    if (variant == 5256 && p.N % 256 == 0) return launch_v2<256, 2, 4, 5>(p, epi, s);      // 160 KiB ring: every byte of LDS
+    if (variant == 4256 && p.N % 256 == 0) return launch_v2<256, 2, 2, 4>(p, epi, s);
+    if (variant == 2128 && p.N % 128 == 0) return launch_v2<128, 2, 2, 3>(p, epi, s);
+#endif
     return 1;
 }
