@@ -30,6 +30,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from keep_amd.distributed import StepExchange, rccl_env, timed_steps       # noqa: E402
+
+rccl_env()        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: what RCCL's multi-process transport needs on these nodes) before HIP starts
+
 from keep_amd import KEEPModel, PROFILE_TAGS, vit_flops_per_tile          # noqa: E402
 from keep_amd.config import KEEPShape                                      # noqa: E402
 from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles    # noqa: E402
@@ -206,7 +210,6 @@ def main():
     use_dist = world > 1 or os.environ.get("KEEP_BENCH_FORCE_DIST") == "1"     # the override exercises the RCCL path on one GPU
     if use_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     log(f"start: world={world} cpus={usable_cpus()} (os.cpu_count={os.cpu_count()})")
@@ -228,41 +231,25 @@ def main():
     pix = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.pixel_dtype]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)        # per-rank tiles, generated on device
     tiles = torch.randn(B, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(pix)
-    # double-buffered so the RCCL all-gather of step i overlaps the encode of step i+1
-    gathered = [torch.empty(world * B, shape.projection_dim, device=dev, dtype=torch.float32) for _ in range(2)] if use_dist else None
-    pending = [None, None]
-    step_no = [0]
+    # keep_amd.distributed.StepExchange: double-buffered, so the RCCL all-gather of step i overlaps the encode of step i+1 (the same
+    # class runs under gloo at world sizes 2 and 3 in tests/test_distributed_cpu.py)
+    exchange = StepExchange(B, shape.projection_dim, dev) if use_dist else None
 
     def step():
         f = model.encode_image(tiles)
         if use_dist:
-            i = step_no[0] & 1
-            if pending[i] is not None:
-                pending[i][0].wait()                       # stream-level wait, frees buffer i (and keeps f alive until then)
-            pending[i] = (dist.all_gather_into_tensor(gathered[i], f, async_op=True), f)
-            step_no[0] += 1
+            exchange.submit(f)
         return f
 
-    def fence():
-        if use_dist:
-            for h in pending:
-                if h is not None:
-                    h[0].wait()
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     def timed(n_steps):
-        fence()
+        if use_dist:
+            return timed_steps(step, n_steps, exchange)          # fence (collectives + barrier + device sync), n steps, fence, MAX over ranks
+        torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
-        fence()
-        el = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
 
     for _ in range(args.warmup):
         step()

@@ -15,6 +15,11 @@
  *     (keep_reserve() up front avoids the allocation a first call would otherwise do)
  *   - a handle is not thread-safe: one handle per GPU per host thread
  *   - no torch / C++ types cross this boundary
+ *   - multi-GPU: one handle per GPU per process.  The path shards without a data-path collective (tiles are independent through
+ *     keep_encode_image and keep_similarity); the one exchange step of a slide -- the all-gather of the per-tile embeddings this
+ *     library writes into the caller's buffer -- is the HOST's: ncclAllGather / torch.distributed.all_gather_into_tensor on that
+ *     buffer, ordered after the encode by the stream both were given (keep_amd/distributed.py).  There is deliberately no
+ *     keep_allgather(): the library neither links RCCL nor owns a communicator.
  */
 #ifndef KEEP_HIP_H
 #define KEEP_HIP_H
@@ -145,12 +150,14 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
 int keep_encode_text(keep_handle* h, const int64_t* input_ids, const int64_t* token_type_ids,
                      const int64_t* attention_mask, int64_t P, int64_t T, float* out, void* stream);
 
-/* 1 if any token / type id of the most recent keep_encode_text on `stream` was out of range (the
- * kernel clamps it; the reference's nn.Embedding would raise IndexError).  Synchronises `stream`. */
+/* 1 if any token / type id of a keep_encode_text call on `stream` SINCE THE LAST TIME THIS RETURNED 1 was out of range (the kernel
+ * clamps it; the reference's nn.Embedding would raise IndexError).  The device-side flag is sticky -- encode calls only ever set it --
+ * and is cleared here, once the host has seen it, so an error can not be lost between calls.  Synchronises `stream`. */
 int keep_token_error(keep_handle* h, void* stream);
-/* The same without a host synchronisation: enqueues a copy of the flag (0 / 1) into `host_flag` (pinned host memory owned by the
- * caller) behind the work already on `stream`; the caller reads it once the stream has passed that point (event, or its next
- * synchronisation).  This is how the reference's CUDA path reports an out-of-range index too: asynchronously. */
+/* The same without a host synchronisation: enqueues a copy of the (sticky) flag into `host_flag` (pinned host memory owned by the
+ * caller, which must stay alive until the stream has passed that point) behind the work already on `stream`.  Does not clear the flag:
+ * a caller that reads a 1 calls keep_token_error() to acknowledge it.  This is how the reference's CUDA path reports an out-of-range
+ * index too: asynchronously. */
 int keep_token_error_async(keep_handle* h, int32_t* host_flag, void* stream);
 
 /* Replaces: `img_feature @ text_feature.T` (keep_inference.py:104), `image_features @ cls`

@@ -5,9 +5,9 @@
     one slide per item, CLAM-style feature files ``<data_source>/pt_files/<slide>.pt`` (tensor [N,768])
     or ``<data_source>/h5_files/<slide>.h5`` (datasets ``features`` [N,768] f32, ``coords`` [N,2]).
     h5py is imported lazily: it is not installed in this image, the ``.pt`` path needs nothing.
-  * ``run_subtyping`` / ``run_detection`` / ``run_segmentation`` <- the three ``run`` functions
-    (subtyping_utils.py:12-35 raw cosine logits; detection_utils.py:12-36 and segment_utils.py:16-42
-    softmax(10*logits)).
+  * ``run_subtyping`` / ``run_detection`` / ``run_segmentation`` <- the three ``run(classifier, dataloader, device)``
+    functions, same arguments and return values (subtyping_utils.py:12-35 raw cosine logits; detection_utils.py:12-36 and
+    segment_utils.py:16-42 softmax(10*logits)); ``keep_amd/wsi_evaluation/*_utils.py`` export each of them as ``run``.
   * ``save_slide_features`` writes what ``encode_image`` produced in the same on-disk formats, so feature
     files can be regenerated with this engine instead of the offline CLAM extraction (README.md:74).
 """
@@ -80,8 +80,8 @@ def save_slide_features(data_source: str, slide_id: str, features: torch.Tensor,
     return path
 
 
-def _loop(model, classifier: torch.Tensor, dataloader, softmax: bool, want_targets: bool):
-    m = _engine(model)
+def _loop(model, classifier: torch.Tensor, dataloader, device, softmax: bool, want_targets: bool):
+    m = _engine(model, classifier, device=device)
     cls_t = classifier.to(m._device, torch.float32).t().contiguous()          # [C, 768] rows, as keep_similarity wants
     logits_all, coords_all, targets_all = {}, {}, {}
     for idx, data in enumerate(dataloader):                                   # batch size is always 1 slide
@@ -99,19 +99,22 @@ def _loop(model, classifier: torch.Tensor, dataloader, softmax: bool, want_targe
 
 
 @torch.no_grad()
-def run_subtyping(model, classifier, dataloader, device=None):
-    """subtyping_utils.py:12-35 -> (raw cosine logits per slide, coords, targets)."""
-    return _loop(model, classifier, dataloader, softmax=False, want_targets=True)
+def run_subtyping(classifier, dataloader, device, model=None):
+    """``run`` of subtyping_utils.py:12-35 -> (raw cosine logits per slide, coords, targets)."""
+    return _loop(model, classifier, dataloader, device, softmax=False, want_targets=True)
 
 
 @torch.no_grad()
-def run_detection(model, classifier, dataloader, device=None):
-    """detection_utils.py:12-36 -> (softmax(10*logits) per slide, coords, targets)."""
-    return _loop(model, classifier, dataloader, softmax=True, want_targets=True)
+def run_detection(classifier, dataloader, device, model=None):
+    """``run`` of detection_utils.py:12-36 -> (softmax(10*logits) per slide, coords, targets)."""
+    return _loop(model, classifier, dataloader, device, softmax=True, want_targets=True)
 
 
 @torch.no_grad()
-def run_segmentation(model, classifier, dataloader, device=None):
-    """segment_utils.py:16-42 -> (softmax(10*logits) per slide, coords)."""
-    l, c, _ = _loop(model, classifier, dataloader, softmax=True, want_targets=False)
+def run_segmentation(classifier, dataloader, device, model=None):
+    """``run`` of segment_utils.py:16-42 -> (softmax(10*logits) per slide, coords)."""
+    l, c, _ = _loop(model, classifier, dataloader, device, softmax=True, want_targets=False)
     return l, c
+
+
+WSI_Classification_Dataset = WSIClassificationDataset        # the reference's spelling (utils.py:11)

@@ -1107,9 +1107,8 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
         if (mask) HIPCHK(h, hipMemcpyAsync(st_mask, mask, nb, hipMemcpyDeviceToDevice, s));
         char key[96];
         snprintf(key, sizeof key, "txt|%lld|%lld|%d|%d", (long long)P, (long long)T, types ? 1 : 0, mask ? 1 : 0);
-        // the flag is cleared outside the graph: a captured 4-byte memset node replayed with a stale value on ROCm 7.2
-        // (spurious token-range errors on 33-99 % of the replays, outputs correct); only kernel nodes are captured
-        HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), s));
+        // (the token-range flag is sticky: set by the embedding kernel, cleared only by keep_token_error once the host has seen it --
+        // so nothing has to be reset per call, and no memset node is captured: one replayed with a stale value on ROCm 7.2)
         rc = graph_run(h, key, s, [&](hipStream_t cs) {
             return txt_chunk(h, st_ids, types ? st_types : nullptr, mask ? st_mask : nullptr, (int)P, (int)T, st_out, cs);
         });
@@ -1119,7 +1118,6 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     }
     int rc = ensure_arena(h, ws_bytes);
     if (rc) return rc;
-    HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), s));
     for (int64_t p0 = 0; p0 < P; p0 += pc_max) {
         const int pc = (int)((P - p0) < pc_max ? (P - p0) : pc_max);
         rc = txt_chunk(h, ids + p0 * T, types ? types + p0 * T : nullptr, mask ? mask + p0 * T : nullptr, pc, (int)T,
@@ -1156,6 +1154,7 @@ int keep_token_error(keep_handle* h, void* stream) {
     int flag = 0;
     HIPCHK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    if (flag) HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), (hipStream_t)stream));     // seen by the host: re-arm
     return flag ? 1 : 0;
 }
 

@@ -13,10 +13,24 @@ un-padded into ``[n_tiles, D]`` with ONE index_select (no per-rank Python copies
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+import os
+import time
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def rccl_env() -> None:
+    """Environment a multi-process RCCL job needs on this platform; call before the first HIP call of the process.
+
+    ``HSA_ENABLE_IPC_MODE_LEGACY=0``: the host driver of the MI355X nodes this was built on only supports dmabuf-based IPC handles.
+    RCCL's intra-node transport (and torch's CUDA-tensor sharing) exchange device buffers between the ranks' processes through
+    ``hipIpcGetMemHandle``; in the legacy IPC mode that call fails with ``invalid argument`` as soon as there is a second process
+    (world size 1 never opens a peer handle, which is why single-GPU runs work without it).  ``setdefault``: an operator's own
+    setting wins.  The rendezvous address defaults to loopback: container host names do not always resolve."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -72,9 +86,17 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
 
 
 def encode_tiles_sharded(encode: Callable[[torch.Tensor], torch.Tensor], n_tiles: int,
-                         load_tiles: Callable[[int, int], torch.Tensor], batch: int = 256, group=None) -> torch.Tensor:
+                         load_tiles: Callable[[int, int], torch.Tensor], batch: int = 256, group=None,
+                         dim: Optional[int] = None, device=None) -> torch.Tensor:
     """Each rank encodes tiles [lo, hi) in batches with ``encode`` (e.g. KEEPModel.encode_image) and all
-    ranks receive the full [n_tiles, D] embedding matrix."""
+    ranks receive the full [n_tiles, D] embedding matrix.  An empty slide (``n_tiles == 0``) has no tile to learn D from:
+    pass ``dim`` (and ``device``) to get the empty ``[0, dim]`` matrix, otherwise it is an error."""
+    if n_tiles < 0 or batch < 1:
+        raise ValueError(f"n_tiles {n_tiles}, batch {batch}")
+    if n_tiles == 0:
+        if dim is None:
+            raise ValueError("n_tiles == 0: pass dim= (the embedding width cannot be learnt from an empty slide)")
+        return torch.empty((0, dim), dtype=torch.float32, device=device)
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
@@ -108,3 +130,64 @@ def encode_tiles_sharded(encode: Callable[[torch.Tensor], torch.Tensor], n_tiles
     owner, off = _owner_and_offset(n_tiles, world, slab.device)
     pos = (off // batch) * (world * batch) + owner * batch + off % batch
     return slab.view(nb * world * batch, -1).index_select(0, pos)
+
+
+# ------------------------------------------------------------------------------------------------
+# The benchmark's step loop (bench.py, N > 1): encode one batch per step, exchange it, time exactly n steps between fences.
+# ------------------------------------------------------------------------------------------------
+class StepExchange:
+    """Double-buffered asynchronous all-gather of one ``[batch, dim]`` result per step: the collective of step i runs while step
+    i+1 is being encoded; buffer i % depth is reused only after its previous collective has been waited for.  Backend-agnostic
+    (``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests); without a process group it degenerates to keeping the last results."""
+
+    def __init__(self, batch: int, dim: int, device, dtype=torch.float32, group=None, depth: int = 2):
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.device = torch.device(device)
+        self.buffers: List[torch.Tensor] = [torch.empty(self.world * batch, dim, device=self.device, dtype=dtype) for _ in range(depth)]
+        self.pending: List[Optional[tuple]] = [None] * depth
+        self.steps = 0
+
+    def submit(self, f: torch.Tensor) -> int:
+        """Queue the exchange of this step's result; returns the index of the buffer it lands in."""
+        i = self.steps % len(self.buffers)
+        self.steps += 1
+        if self.pending[i] is not None:
+            self.pending[i][0].wait()              # stream-level wait on GPUs: frees buffer i (and keeps the old `f` alive until then)
+        if self.distributed:
+            self.pending[i] = (dist.all_gather_into_tensor(self.buffers[i], f, group=self.group, async_op=True), f)
+        else:
+            self.buffers[i].copy_(f)
+        return i
+
+    def gathered(self, i: int) -> torch.Tensor:
+        if self.pending[i] is not None:
+            self.pending[i][0].wait()
+        return self.buffers[i]
+
+    def fence(self) -> None:
+        """Every queued collective done on every rank, every device idle: both ends of a timed region."""
+        for k, h in enumerate(self.pending):
+            if h is not None:
+                h[0].wait()
+                self.pending[k] = None
+        if self.distributed:
+            dist.barrier(group=self.group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+
+def timed_steps(step: Callable[[], None], n_steps: int, exchange: StepExchange) -> float:
+    """Seconds for exactly ``n_steps`` calls of ``step`` between two fences (barrier + device synchronisation), MAX over the ranks."""
+    exchange.fence()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        step()
+    exchange.fence()
+    el = time.perf_counter() - t0
+    if exchange.distributed:
+        t = torch.tensor([el], device=exchange.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=exchange.group)
+        el = float(t.item())
+    return el

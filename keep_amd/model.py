@@ -16,7 +16,8 @@ import ctypes as C
 import json
 import math
 import os
-from typing import Dict, Mapping, Optional, Union
+import weakref
+from typing import Dict, List, Mapping, Optional, Union
 
 import torch
 
@@ -38,6 +39,10 @@ def _stream(device: torch.device):
 
 class KEEPModel:
     """Drop-in for the reference ``KEEPModel`` (inference only)."""
+
+    # engines that own a handle, newest last: the slide-level functions of keep_amd.wsi take no model argument (the reference's are plain
+    # torch code, WSI_evaluation/utils.py:107-146) and find the engine of their device here (keep_amd.model.engine_for)
+    _live: "List[weakref.ref]" = []
 
     def __init__(self, config: Optional[Union[KEEPShape, Mapping, str]] = None, precision: str = DEFAULT_PRECISION,
                  towers=("image", "text")):
@@ -64,7 +69,8 @@ class KEEPModel:
         # or by check_errors() -- no synchronisation, which is also how the reference's CUDA path reports it (device-side assert);
         # False: never checked.  The reference's WSI scripts make thousands of one-prompt calls, so the default is "lazy".
         self.check_token_ids = "lazy"
-        self._pending_token_check = None
+        self._pending_token_checks = []   # [(pinned int32 flag, event)] in issue order; the device flag is sticky, so none can be lost
+        self._flag_pool = []              # pinned buffers are recycled only after their copy has landed
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
 
@@ -94,6 +100,7 @@ class KEEPModel:
             raise _lib.KeepHipError(f"keep_create(device={idx}) failed with code {rc}")
         self._handle = h
         self._device = torch.device("cuda", idx)
+        KEEPModel._live[:] = [r for r in KEEPModel._live if r() is not None and r() is not self] + [weakref.ref(self)]
         for k, v in self._options.items():
             _lib.check(h, lib.keep_set_option(h, k.encode(), float(v)), k)
 
@@ -187,6 +194,7 @@ class KEEPModel:
                 raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\tMissing key(s) in state_dict: " + ", ".join(missing)
                                    + ' (construct with towers=("image",) / ("text",) for a single-tower engine)')
         self._loaded = True
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1      # invalidates per-model prompt caches (keep_amd.wsi)
 
     @classmethod
     def from_pretrained(cls, path: str, precision: str = DEFAULT_PRECISION, **_ignored) -> "KEEPModel":
@@ -366,11 +374,13 @@ class KEEPModel:
         _lib.check(self._handle, lib.keep_encode_text(self._handle, _ptr(ids_d), _ptr(typ_d), _ptr(msk_d), P, T,
                                                       _ptr(out), st), "encode_text")
         if self.check_token_ids == "lazy":
-            flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            if len(self._pending_token_checks) >= 64:                  # bound the queue: wait for the oldest copies
+                self.check_errors(wait=True)
+            flag = self._flag_pool.pop() if self._flag_pool else torch.zeros(1, dtype=torch.int32).pin_memory()
             _lib.check(self._handle, lib.keep_token_error_async(self._handle, _ptr(flag), st), "token_error_async")
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self._device))
-            self._pending_token_check = (flag, ev)
+            self._pending_token_checks.append((flag, ev))
         elif self.check_token_ids and lib.keep_token_error(self._handle, st) == 1:
             raise IndexError("index out of range in self (input_ids / token_type_ids outside the embedding tables)")
         if src_dev == self._device:
@@ -381,17 +391,25 @@ class KEEPModel:
 
     def check_errors(self, wait: bool = True):
         """Raise the IndexError of an earlier ``encode_text`` call whose token ids were out of range (lazy checking).  Called by
-        every engine entry point with ``wait=False`` (only looks at results that have already arrived)."""
-        pend = self._pending_token_check
-        if pend is None:
+        every engine entry point with ``wait=False`` (only looks at copies that have already landed).  The device-side flag is
+        sticky and every call's copy is queued, so an error is reported by the first check after it -- never dropped."""
+        pend = self._pending_token_checks
+        if not pend:
             return
-        flag, ev = pend
         if wait:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        self._pending_token_check = None
-        if int(flag.item()) != 0:
+            pend[-1][1].synchronize()
+        bad = False
+        while pend and pend[0][1].query():
+            flag, _ = pend.pop(0)
+            bad = bad or int(flag.item()) != 0
+            self._flag_pool.append(flag)
+        if bad:
+            # acknowledge (clears the sticky flag); copies still in flight were taken before the clear and would repeat the report
+            _lib.load().keep_token_error(self._handle, _stream(self._device))
+            for flag, ev in pend:
+                ev.synchronize()
+                self._flag_pool.append(flag)
+            pend.clear()
             raise IndexError("index out of range in self (input_ids / token_type_ids of an earlier encode_text call were outside "
                              "the embedding tables)")
 
@@ -442,6 +460,7 @@ class KEEPModel:
         return out
 
     def _ready_device(self):
+        self.check_errors(wait=False)
         if not self._handle.value:
             self._create(torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0))
 
@@ -461,6 +480,35 @@ class KEEPModel:
         ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
         _lib.check(self._handle, _lib.load().keep_profile_read(self._handle, tag.encode(), C.byref(ms), C.byref(n), C.byref(fl)), tag)
         return ms.value, n.value, fl.value
+
+
+_bare_engines: Dict[int, "KEEPModel"] = {}
+
+
+def engine_for(device=None, model=None) -> "KEEPModel":
+    """The engine the model-free slide-level functions run on: ``model`` if given (a KEEPModel or the reference's ``KEEP_model``
+    dict), else the most recently created live engine on ``device`` (default: the current GPU), else a weight-less handle on
+    that device (similarity / screening / refine kernels need no weights)."""
+    if model is not None:
+        m = model["model"] if isinstance(model, Mapping) else model
+        if not isinstance(m, KEEPModel):
+            raise TypeError("expected a keep_amd.KEEPModel (or the reference's KEEP_model dict holding one)")
+        m._ready_device()
+        return m
+    if not torch.cuda.is_available():
+        raise _lib.KeepHipError("no GPU visible: keep_amd has no CPU execution path")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.type != "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())      # features on the host: computed on the current GPU, returned to the host
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    for r in reversed(KEEPModel._live):
+        m = r()
+        if m is not None and m._handle.value and m._device is not None and m._device.index == idx:
+            return m
+    m = KEEPModel()
+    m._create(torch.device("cuda", idx))
+    _bare_engines[idx] = m                    # keeps the weight-less handle alive (the registry only holds weak references)
+    return m
 
 
 PROFILE_TAGS = ("vit.im2col", "vit.patch", "vit.ln", "vit.qkv", "vit.attn", "vit.proj", "vit.fc1", "vit.fc2",

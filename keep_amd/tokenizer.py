@@ -40,13 +40,16 @@ class Encoding(dict):
 
 
 def _is_whitespace(ch: str) -> bool:
-    return ch in " \t\n\r" or unicodedata.category(ch) == "Zs"
+    # the tokenizers crate tests Rust's char::is_whitespace (Unicode White_Space): the separator categories Zs, Zl (U+2028) and Zp (U+2029);
+    # the White_Space members of category Cc (VT, FF, NEL ...) never get here -- the clean-up removes control characters first
+    return ch in " \t\n\r" or unicodedata.category(ch) in ("Zs", "Zl", "Zp")
 
 
 def _is_control(ch: str) -> bool:
     if ch in "\t\n\r":
         return False
-    return unicodedata.category(ch).startswith("C")
+    # Cc / Cf / Co as in the crate's `is_other()`; UNASSIGNED code points (Cn) are kept there and end up as [UNK]
+    return unicodedata.category(ch) in ("Cc", "Cf", "Co")
 
 
 def _is_punctuation(ch: str) -> bool:
@@ -164,7 +167,8 @@ class WordPieceTokenizer:
 
     def __call__(self, texts: Union[str, Sequence[str]], max_length: Optional[int] = None, padding=False, truncation=False,
                  return_tensors: Optional[str] = None, **_) -> Encoding:
-        if isinstance(texts, str):
+        single = isinstance(texts, str)
+        if single:
             texts = [texts]
         rows = []
         for t in texts:
@@ -190,6 +194,8 @@ class WordPieceTokenizer:
             enc = {k: torch.tensor(v, dtype=torch.int64).reshape(len(rows), -1) for k, v in enc.items()}
         elif return_tensors is not None:
             raise ValueError(f"return_tensors={return_tensors!r}: only 'pt' is supported")
+        elif single:
+            enc = {k: v[0] for k, v in enc.items()}      # a str in, flat lists out -- as the HF tokenizer does without return_tensors
         return Encoding(enc)
 
 

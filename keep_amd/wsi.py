@@ -1,24 +1,26 @@
 """GPU versions of the reference's slide-level zero-shot logic.
 
-Function names, arguments and return values mirror ``WSI_evaluation/utils.py``,
-``subtyping_utils.py``, ``detection_utils.py`` and ``segment_utils.py`` so the three
-``zeroshot_*_WSI.py`` scripts can import them instead; the per-classifier / per-tile Python loops of
-the reference (one GEMM + ``.item()`` sync per prompt set, one ``.cpu()`` per tile) become a handful of
-kernel launches through the C ABI (``keep_similarity``, ``keep_prompt_scores``, ``keep_refine``).
+Every public function has the NAME, POSITIONAL ARGUMENTS, DEFAULTS and RETURN VALUE of its counterpart in
+``WSI_evaluation/utils.py``, ``subtyping_utils.py``, ``detection_utils.py`` and ``segment_utils.py`` (cited per function), so
+the call sites of the three ``zeroshot_*_WSI.py`` scripts run unchanged (``keep_amd/wsi_evaluation/`` re-exports them under the
+reference's module names).  The per-classifier / per-tile Python loops of the reference (one GEMM + ``.item()`` sync per prompt
+set, one ``.cpu()`` per tile) become a handful of kernel launches through the C ABI (``keep_similarity``, ``keep_prompt_scores``,
+``keep_refine``).
 
-``model`` is a :class:`keep_amd.KEEPModel`; where the reference passes ``KEEP_model`` (a dict with
-``'model'`` and ``'tokenizer'``) the same dict is accepted.
+The reference's functions are plain torch code and take no model; here the kernels belong to an engine handle, which is found
+from the device (``keep_amd.model.engine_for``: the live ``KEEPModel`` on that GPU, or a weight-less handle).  An optional
+keyword ``model=`` pins it (a ``KEEPModel`` or the reference's ``KEEP_model`` dict).
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import Dict, List, Mapping, Optional, Sequence, Tuple, Union
+import weakref
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
 from . import _lib
-from .model import KEEPModel, _ptr, _stream
+from .model import KEEPModel, _ptr, _stream, engine_for
 
 
 # ------------------------------------------------------------------------------------------------
@@ -46,25 +48,44 @@ class TextEmbeddingCache:
         return torch.stack([self._cache[t] for t in texts])
 
 
+# one cache per (model, tokenizer, weights): the reference scripts call get_zeroshot_classifier once per prompt set with the same
+# KEEP_model dict (zeroshot_subtyping_WSI.py:59-62), so repeated strings are embedded once without any change to the call site
+_auto_caches: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+PROMPT_CACHE = True          # False: embed every string on every call, exactly as the reference does
+
+
+def _cache_for(KEEP_model, device) -> TextEmbeddingCache:
+    m, tok = KEEP_model["model"], KEEP_model["tokenizer"]
+    if not PROMPT_CACHE or not isinstance(m, KEEPModel):
+        return TextEmbeddingCache(KEEP_model, device)
+    key = (id(tok), getattr(m, "_weights_epoch", 0), str(device))
+    slot = _auto_caches.get(m)
+    if slot is None or slot[0] != key:
+        slot = (key, TextEmbeddingCache(KEEP_model, device))
+        _auto_caches[m] = slot
+    return slot[1]
+
+
 def zero_shot_classifier(KEEP_model, classnames, templates, device, cache: Optional[TextEmbeddingCache] = None):
     """utils.py:64-84.  Returns [feat_dim, num_classes]."""
-    cache = cache or TextEmbeddingCache(KEEP_model, device)
+    cache = cache or _cache_for(KEEP_model, device)
     weights = []
-    for classname in classnames:
-        if isinstance(templates, list):
-            texts = [t.replace("CLASSNAME", classname) for t in templates]
-        else:
-            texts = [templates.replace("CLASSNAME", classname)]
-        # the reference keeps only row 0 of the batch (`encode_text(text_inputs)[0]`, utils.py:74)
-        class_embeddings = cache.embed(texts)[0].unsqueeze(0)
-        class_embedding = torch.nn.functional.normalize(class_embeddings, dim=-1).mean(dim=0)
-        class_embedding = class_embedding / class_embedding.norm()
-        weights.append(class_embedding)
+    with torch.no_grad():
+        for classname in classnames:
+            if isinstance(templates, list):
+                texts = [t.replace("CLASSNAME", classname) for t in templates]
+            else:
+                texts = [templates.replace("CLASSNAME", classname)]
+            # the reference keeps only row 0 of the batch (`encode_text(text_inputs)[0]`, utils.py:74)
+            class_embeddings = cache.embed(texts)[0].unsqueeze(0)
+            class_embedding = torch.nn.functional.normalize(class_embeddings, dim=-1).mean(dim=0)
+            class_embedding = class_embedding / class_embedding.norm()
+            weights.append(class_embedding)
     return torch.stack(weights, dim=1).to(device)
 
 
 def get_zeroshot_classifier(model, label_map, prompts, device, add_normal=False, cache: Optional[TextEmbeddingCache] = None):
-    """utils.py:86-104."""
+    """utils.py:86-104 (``model`` is the reference's ``KEEP_model`` dict: {'model', 'tokenizer', ...})."""
     classnames, templates = prompts["classnames"], prompts["templates"]
     idx_to_class = {v: k for k, v in label_map.items()}
     n_classes = len(idx_to_class)
@@ -82,7 +103,7 @@ def build_classifier_bank(KEEP_model, label_map, prompts, device, add_normal=Fal
     once and the per-class normalise -> mean -> renormalise (utils.py:76-80) done for all K x C columns in three tensor
     ops instead of K x C x 4 tiny launches.  ``prompts``: the parsed prompt JSON ({"0": {"classnames", "templates"}, ...})
     or a list of such entries.  Returns K tensors [feat_dim, C] (views of one [K, feat_dim, C] tensor)."""
-    cache = cache or TextEmbeddingCache(KEEP_model, device)
+    cache = cache or _cache_for(KEEP_model, device)
     entries = [prompts[str(i)] for i in range(len(prompts))] if isinstance(prompts, Mapping) else list(prompts)
     idx_to_class = {v: k for k, v in label_map.items()}
     if add_normal:
@@ -100,12 +121,16 @@ def build_classifier_bank(KEEP_model, label_map, prompts, device, add_normal=Fal
 
 
 # ------------------------------------------------------------------------------------------------
-def _engine(model) -> KEEPModel:
-    m = model["model"] if isinstance(model, Mapping) else model
-    if not isinstance(m, KEEPModel):
-        raise TypeError("expected a keep_amd.KEEPModel (or the reference's KEEP_model dict holding one)")
-    m._ready_device()
-    return m
+def _engine(model=None, *tensors, device=None) -> KEEPModel:
+    """The engine of a call: ``model`` if pinned, else the one that lives on the device of ``device`` / the first GPU tensor."""
+    if model is not None:
+        return engine_for(model=model)
+    if device is None:
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.device.type == "cuda":
+                device = t.device
+                break
+    return engine_for(device=device)
 
 
 def _normalized(m: KEEPModel, feats: torch.Tensor) -> torch.Tensor:
@@ -117,19 +142,19 @@ def _normalized(m: KEEPModel, feats: torch.Tensor) -> torch.Tensor:
     return f
 
 
-def rank_cls_score(model, logits: torch.Tensor) -> float:
-    """utils.py:107-117 on a ready [N,C] logits matrix."""
-    m = _engine(model)
+def rank_cls_score(logits: torch.Tensor, model=None) -> float:
+    """utils.py:107-117 on a ready [N,C] logits matrix -> Python float."""
+    m = _engine(model, logits)
     x = logits.to(m._device, torch.float32).contiguous()
     eye = torch.eye(x.shape[1], device=m._device)
     # scores of ONE classifier whose logits are given: run the group kernel with K = 1 on logits @ I
-    return float(prompt_scores(m, x, [eye], pre_normalized=True, _logits_given=True)[0])
+    return float(prompt_scores(x, [eye], pre_normalized=True, model=m, _logits_given=True)[0])
 
 
-def prompt_scores(model, tile_features: torch.Tensor, classifiers: Sequence[torch.Tensor], pre_normalized: bool = False,
+def prompt_scores(tile_features: torch.Tensor, classifiers: Sequence[torch.Tensor], pre_normalized: bool = False, model=None,
                   _logits_given: bool = False) -> torch.Tensor:
-    """rank_cls_score of every classifier in one pass -> fp32 [K] on the engine's device."""
-    m = _engine(model)
+    """rank_cls_score of every classifier in one pass (the loop at utils.py:127-130) -> fp32 [K] on the engine's device."""
+    m = _engine(model, tile_features, *classifiers[:1])
     K, (D, Cc) = len(classifiers), classifiers[0].shape
     bank = torch.stack([c.to(m._device, torch.float32).t() for c in classifiers]).reshape(K * Cc, D).contiguous()
     f = tile_features.to(m._device, torch.float32).contiguous() if pre_normalized else _normalized(m, tile_features)
@@ -146,17 +171,16 @@ def prompt_scores(model, tile_features: torch.Tensor, classifiers: Sequence[torc
     return scores
 
 
-def zero_shot_prompt_select(model, classifiers, tile_features, topn, device=None):
-    """utils.py:119-146: score every prompt classifier on the slide, keep the top-n, sum and renormalise.
-
-    ``model`` is an extra leading argument compared with the reference (which only used torch ops)."""
-    m = _engine(model)
-    scores = prompt_scores(m, tile_features, classifiers)
-    # same tie behaviour as the reference: torch.sort(descending=True) on a CPU tensor of Python floats
+def zero_shot_prompt_select(classifiers, tile_features, topn, device, model=None):
+    """utils.py:119-146: score every prompt classifier on the slide, keep the top-n, sum and renormalise -> [feat_dim, C] on
+    the device of the classifiers (``torch.zeros_like(classifiers[0])``, utils.py:141)."""
+    m = _engine(model, device=device)
+    scores = prompt_scores(tile_features, classifiers, model=m)
+    # same tie behaviour as the reference: torch.sort(descending=True) on a CPU tensor of Python floats (utils.py:139)
     _, index = torch.sort(torch.tensor(scores.cpu().tolist()), descending=True)
-    merge = torch.zeros_like(classifiers[0].to(m._device, torch.float32))
+    merge = torch.zeros_like(classifiers[0], dtype=torch.float32)
     for cls_index in index[0:topn]:
-        merge += classifiers[int(cls_index)].to(m._device, torch.float32)
+        merge += classifiers[int(cls_index)].to(merge.device, torch.float32)
     return torch.nn.functional.normalize(merge, p=2, dim=0)
 
 
@@ -172,6 +196,23 @@ def random_prompt_ensemble(classifiers: Sequence[torch.Tensor], topn: int) -> to
     return torch.nn.functional.normalize(ensemble_cls, p=2, dim=0)
 
 
+def cood2str(cood):
+    """utils.py:148-149."""
+    return str(cood[0]) + "_" + str(cood[1])
+
+
+def str2cood(s):
+    """utils.py:150-151."""
+    return [int(item) for item in s.split("_")]
+
+
+def accuracy(logits, target, topk=(1,)):
+    """utils.py:153-156."""
+    pred = logits.topk(max(topk), 1, True, True)[1].t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [float(correct[:k].reshape(-1).float().sum(0, keepdim=True).cpu().numpy()) for k in topk]
+
+
 # ------------------------------------------------------------------------------------------------
 def _probs(m: KEEPModel, classifier: torch.Tensor, tile_features: torch.Tensor) -> torch.Tensor:
     """softmax(10 * normalize(feat) @ classifier, dim=1) -- subtyping_utils.py:69-72."""
@@ -179,10 +220,10 @@ def _probs(m: KEEPModel, classifier: torch.Tensor, tile_features: torch.Tensor) 
     return m.similarity(f, classifier.t().contiguous(), scale=10.0, mode="softmax")
 
 
-def refine(model, probs: torch.Tensor, tile_coords, patch_size: int, overlap: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def refine(probs: torch.Tensor, tile_coords, patch_size: int, overlap: bool, model=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Core of the three ``refine_seg`` variants.  Returns (coords [U,2], mean probs [U,C], index [U]) for the
     U distinct coordinates in first-seen order (the key order of the reference's dicts)."""
-    m = _engine(model)
+    m = _engine(model, probs)
     p = probs.to(m._device, torch.float32).contiguous()
     coords = torch.as_tensor(np.asarray(tile_coords)).to(torch.int64)
     lim = 2 ** 31 - 1 - abs(int(patch_size))
@@ -199,10 +240,20 @@ def refine(model, probs: torch.Tensor, tile_coords, patch_size: int, overlap: bo
     return coords[idx], out[idx], idx
 
 
-def zero_shot_subtyping(model, classifier, tile_features, tile_coords, patch_size=256, overlap=True):
-    """subtyping_utils.py:67-83 -> slide label (int tensor, like the reference's ``max_label``)."""
-    m = _engine(model)
-    _, mean, _ = refine(m, _probs(m, classifier, tile_features), tile_coords, patch_size, overlap)
+def _keys(coords: torch.Tensor) -> List[str]:
+    return [f"{x}_{y}" for x, y in coords.cpu().tolist()]
+
+
+def refine_seg_subtyping(logits_slide, coords_slide, patch_size=224, overlap=True, model=None) -> Dict[str, int]:
+    """``refine_seg`` of subtyping_utils.py:38-65: {"x_y": predicted class} in first-seen order."""
+    coords, mean, _ = refine(logits_slide, coords_slide, patch_size, overlap, model=model)
+    return dict(zip(_keys(coords), mean.argmax(dim=1).cpu().tolist()))
+
+
+def zero_shot_subtyping(classifier, tile_features, tile_coords, patch_size=256, overlap=True, model=None):
+    """subtyping_utils.py:67-83 -> slide label (0-d int64 tensor, the reference's ``max_label``)."""
+    m = _engine(model, tile_features, classifier)
+    _, mean, _ = refine(_probs(m, classifier, tile_features), tile_coords, patch_size, overlap, model=m)
     pred = mean.argmax(dim=1)
     C_ = classifier.shape[1]
     # (preds == ix).sum() / len(preds) in float64, as the numpy expression at subtyping_utils.py:80
@@ -211,17 +262,38 @@ def zero_shot_subtyping(model, classifier, tile_features, tile_coords, patch_siz
     return max_label
 
 
-def zero_shot_detection(model, classifier, tile_features, tile_coords, patch_size=256, overlap=False, threshold=0.5):
-    """detection_utils.py:88-100 -> tumour-tile ratio."""
-    m = _engine(model)
-    _, mean, _ = refine(m, _probs(m, classifier, tile_features), tile_coords, patch_size, overlap)
-    return float((mean[:, 1] > threshold).sum().item()) / mean.shape[0]
+def refine_seg_detection(logits_slide, coords_slide, patch_size=224, threshold=0.5, overlap=True, model=None):
+    """``refine_seg`` of detection_utils.py:39-74: ({"x_y": 0/1}, {"x_y": tumour probability})."""
+    coords, mean, _ = refine(logits_slide, coords_slide, patch_size, overlap, model=model)
+    keys, p1 = _keys(coords), mean[:, 1]
+    return dict(zip(keys, (p1 > threshold).to(torch.int64).cpu().tolist())), dict(zip(keys, p1.cpu().tolist()))
 
 
-def zero_shot_segment_probs(model, classifier, tile_features, tile_coords, patch_size=224, overlap=True) -> Dict[str, float]:
-    """segment_utils.py:44-52 + refine_seg :63-89 -> {"x_y": tumour probability} in first-seen order
-    (the AUC / Dice evaluation against openslide masks that follows in the reference is out of scope)."""
-    m = _engine(model)
-    coords, mean, _ = refine(m, _probs(m, classifier, tile_features), tile_coords, patch_size, overlap)
-    c, v = coords.cpu().tolist(), mean[:, 1].cpu().tolist()
-    return {f"{x}_{y}": p for (x, y), p in zip(c, v)}
+def zero_shot_detection(classifier, tile_features, tile_coords, patch_size=256, overlap=False, model=None):
+    """detection_utils.py:88-100 -> tumour-tile ratio (float)."""
+    m = _engine(model, tile_features, classifier)
+    _, mean, _ = refine(_probs(m, classifier, tile_features), tile_coords, patch_size, overlap, model=m)
+    return float((mean[:, 1] > 0.5).sum().item()) / mean.shape[0]
+
+
+def refine_seg_segment(logits_slide, coords_slide, patch_size=224, overlap=True, model=None) -> Dict[str, float]:
+    """``refine_seg`` of segment_utils.py:63-89: {"x_y": tumour probability} in first-seen order."""
+    coords, mean, _ = refine(logits_slide, coords_slide, patch_size, overlap, model=model)
+    return dict(zip(_keys(coords), mean[:, 1].cpu().tolist()))
+
+
+def zero_shot_segment_probs(classifier, tile_features, tile_coords, patch_size=224, overlap=True, model=None) -> Dict[str, float]:
+    """segment_utils.py:44-52 + refine_seg :63-89: the dense per-tile tumour-probability map of ``zero_shot_segment``."""
+    m = _engine(model, tile_features, classifier)
+    return refine_seg_segment(_probs(m, classifier, tile_features), tile_coords, patch_size, overlap, model=m)
+
+
+def zero_shot_segment(classifier, tile_features, tile_coords, mask_path, patch_size=224, overlap=True, model=None):
+    """segment_utils.py:44-60.  The probability map is computed here; the AUC / Dice evaluation against an openslide mask that
+    follows in the reference (``eval_seg_auc`` / ``eval_seg_coarse``, :91-152) is out of scope (needs
+    openslide and real WSI masks) -- pass ``mask_path=None`` to get the map, which is what those two functions consume."""
+    probs_all_refined = zero_shot_segment_probs(classifier, tile_features, tile_coords, patch_size, overlap, model=model)
+    if mask_path is None:
+        return probs_all_refined
+    raise NotImplementedError("AUC / Dice against an openslide mask (segment_utils.py:91-152) is outside the hot path; "
+                              "call with mask_path=None and feed the returned map to the reference's eval_seg_auc / eval_seg_coarse")

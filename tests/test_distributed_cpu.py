@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from keep_amd.distributed import all_gather_rows, encode_tiles_sharded, shard_bounds, shard_capacity
+from keep_amd.distributed import StepExchange, all_gather_rows, encode_tiles_sharded, rccl_env, shard_bounds, shard_capacity, timed_steps
 
 
 def test_shard_bounds_cover_everything_once():
@@ -87,3 +87,82 @@ def test_single_process_passthrough():
     assert all_gather_rows(x, 5) is x
     with pytest.raises(ValueError):
         all_gather_rows(x, 6)
+
+
+# ------------------------------------------------------------------ bench.py's N > 1 step loop (keep_amd.distributed.StepExchange / timed_steps)
+def _bench_loop_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, D, steps = 8, 4, 7
+        g = torch.Generator().manual_seed(100 + rank)                     # per-rank tiles, as bench.py draws them
+        tiles = torch.randn(B, 3, 4, 4, generator=g)
+        ex = StepExchange(B, D, "cpu")
+        seen = []
+
+        def step():
+            f = fake_encode(tiles) + float(ex.steps)                      # the step number makes a stale buffer detectable
+            seen.append(ex.submit(f))
+
+        import time
+        el = timed_steps(step, steps, ex)
+        ok = ex.steps == steps and seen == [i % 2 for i in range(steps)] and el > 0
+        ok = ok and all(p is None for p in ex.pending)                    # the closing fence waited for every collective
+        # after the closing fence the two buffers hold the last two steps of EVERY rank, in rank order
+        for back in (1, 2):
+            i = (steps - back) % 2
+            want = torch.cat([fake_encode(torch.randn(B, 3, 4, 4, generator=torch.Generator().manual_seed(100 + r))) + float(steps - back)
+                              for r in range(world)])
+            ok = ok and torch.equal(ex.gathered(i), want)
+        # MAX over ranks: a slow rank sets everybody's time
+        slow = timed_steps(lambda: time.sleep(0.05 if rank == world - 1 else 0.0) or step(), 3, ex)
+        ok = ok and slow >= 0.15
+        q.put((rank, bool(ok), el, slow))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_step_loop_double_buffer_fence_and_max_reduce(world):
+    """The loop bench.py times at N > 1: asynchronous double-buffered all-gather per step, fence (collectives + barrier) on both
+    sides, elapsed = MAX over ranks -- on gloo with a stand-in encoder."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = [q.get(timeout=5) for _ in range(world)]
+    assert all(r[1] for r in res), res
+    assert len({round(r[3], 9) for r in res}) == 1, "every rank must report the same (max) time"
+
+
+def test_step_exchange_without_a_process_group():
+    ex = StepExchange(4, 3, "cpu")
+    for k in range(3):
+        i = ex.submit(torch.full((4, 3), float(k)))
+        assert torch.equal(ex.gathered(i), torch.full((4, 3), float(k)))
+    assert timed_steps(lambda: ex.submit(torch.zeros(4, 3)), 2, ex) > 0
+
+
+def test_empty_slide_and_bad_arguments():
+    out = encode_tiles_sharded(fake_encode, 0, lambda a, b: torch.empty(0, 3, 4, 4), batch=8, dim=4)
+    assert out.shape == (0, 4)
+    with pytest.raises(ValueError):
+        encode_tiles_sharded(fake_encode, 0, lambda a, b: torch.empty(0, 3, 4, 4), batch=8)
+    with pytest.raises(ValueError):
+        encode_tiles_sharded(fake_encode, 5, lambda a, b: torch.empty(0, 3, 4, 4), batch=0)
+
+
+def test_rccl_env_defaults(monkeypatch):
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    rccl_env()
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
+    rccl_env()
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"          # an operator's setting wins

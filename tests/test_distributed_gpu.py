@@ -28,7 +28,8 @@ def nccl_world1():
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from keep_amd.distributed import rccl_env
+    rccl_env()                                   # dmabuf IPC (what RCCL needs across processes on these nodes) + loopback rendezvous
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield dist
@@ -58,7 +59,7 @@ def test_sharded_encode_through_rccl_matches_direct_call(nccl_world1):
 
 def test_bench_distributed_leg_runs_on_nccl():
     env = dict(os.environ, KEEP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))      # bench.py sets the RCCL environment itself (keep_amd.distributed.rccl_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
                         "--no-cpu-baseline", "--no-breakdown", "--no-configs"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -303,6 +303,16 @@ def test_graph_replay_is_bit_identical(small):
     with pytest.raises(IndexError):
         m.encode_image(x1)
     m.encode_image(x1)                            # reported once
+    # the WSI pattern (thousands of one-prompt calls, then similarity): an error in the middle is reported by one of the later calls --
+    # the device flag is sticky and every call's check is queued, so nothing is overwritten or dropped
+    with pytest.raises(IndexError):
+        m.encode_text(bad)
+        feats = [m.encode_text({k: v[:1].contiguous() for k, v in toks.items()}) for _ in range(6)]
+        torch.cuda.synchronize()
+        m.similarity(feats[0], feats[1])
+    m.similarity(m.encode_text(toks), m.encode_text(toks))      # acknowledged: clean again
+    torch.cuda.synchronize()
+    m.check_errors()
     m.check_token_ids = True
     with pytest.raises(IndexError):
         m.encode_text(bad)

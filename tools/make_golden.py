@@ -212,6 +212,67 @@ def golden_wsi(seed: int = 7):
                         seg_keys=seg_keys, seg_probs=seg_vals)
 
 
+def golden_wsi_callers(seed: int = 9):
+    """Rows a9 / a10 / a17 pinned to the reference's OWN functions: `zero_shot_classifier`, `get_zeroshot_classifier`
+    (WSI_evaluation/utils.py:64-104) through a stand-in KEEP_model whose text tower is transformers.BertModel -- the class the
+    reference instantiates -- on seeded weights and a deterministic stand-in tokenizer; and the three `run(classifier,
+    dataloader, device)` loops (subtyping_utils.py:12, detection_utils.py:12, segment_utils.py:16) over the reference's
+    `WSI_Classification_Dataset` (utils.py:11-61) on .pt feature files and a torch DataLoader."""
+    import contextlib, io, tempfile
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from standins import (CALLER_DIAG_MAP, CALLER_LABEL_MAP, CALLER_PROMPTS, CALLER_SLIDES, HashTokenizer, caller_slide_features)
+    r_utils, r_sub, r_det, r_seg = import_reference_wsi()
+    sd = synth_state_dict(small_shape(1, 2), seed=seed, vision=False)
+    bert = hf_bert_from_sd(sd, 2, "eager")
+
+    class RefTextModel:                           # keep_inference.py:60-62 on the HF module
+        def encode_text(self, text_inputs):
+            return torch.nn.functional.normalize(bert(**text_inputs).pooler_output, dim=-1)
+
+    KEEP_model = {"model": RefTextModel(), "tokenizer": HashTokenizer()}
+    out = {}
+    with torch.no_grad():
+        for i, p in enumerate(CALLER_PROMPTS):
+            out[f"cls_normal_{i}"] = r_utils.get_zeroshot_classifier(KEEP_model, CALLER_LABEL_MAP, p, "cpu", add_normal=True).numpy()
+            out[f"cls_plain_{i}"] = r_utils.get_zeroshot_classifier(KEEP_model, CALLER_LABEL_MAP, p, "cpu").numpy()
+        names = ["lung adenocarcinoma", "normal tissue"]
+        out["zsc_str"] = r_utils.zero_shot_classifier(KEEP_model, names, "an H&E image of CLASSNAME.", "cpu").numpy()
+        out["zsc_list"] = r_utils.zero_shot_classifier(KEEP_model, names, ["CLASSNAME.", "a photo of CLASSNAME."], "cpu").numpy()
+        # oracle agreement: column c = renormalised embedding of the filled (first) template
+        ref = O.encode_text(sd, HashTokenizer()(["an H&E image of normal tissue."]))[0]
+        assert (torch.from_numpy(out["zsc_str"][:, 1]) - ref / ref.norm()).abs().max() < 2e-6
+    assert out["cls_normal_0"].shape == (768, 4) and out["cls_plain_0"].shape == (768, 3)
+
+    feats = caller_slide_features()
+    g = torch.Generator().manual_seed(seed + 1)
+    cls3 = torch.nn.functional.normalize(torch.randn(768, 3, generator=g), dim=0)
+    cls2 = cls3[:, :2].contiguous()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "pt_files"))
+        for sid, f in feats.items():
+            torch.save(f, os.path.join(tmp, "pt_files", sid + ".pt"))
+        df = pd.DataFrame([{"slide_id": sid, "Diagnosis": d} for sid, _, d in CALLER_SLIDES])
+        ds = r_utils.WSI_Classification_Dataset(df, tmp, use_h5=False, label_map=CALLER_DIAG_MAP)
+        dl = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            sub_logits, sub_coords, sub_targets = r_sub.run(cls3, dl, "cpu")
+            det_probs, _, det_targets = r_det.run(cls2, dl, "cpu")
+            seg_probs, seg_coords = r_seg.run(cls2, dl, "cpu")
+    assert sub_targets == det_targets == {sid: CALLER_DIAG_MAP[d] for sid, _, d in CALLER_SLIDES}
+    assert all(c == [] for c in sub_coords.values()) and list(seg_coords) == [sid for sid, _, _ in CALLER_SLIDES]
+    for sid, f in feats.items():
+        refl = O.l2_normalize(f) @ cls3
+        assert (sub_logits[sid] - refl).abs().max() < 1e-6
+        assert (det_probs[sid] - O.sim_softmax(O.l2_normalize(f) @ cls2, 10.0)).abs().max() < 1e-6
+        out[f"run_sub_{sid}"] = sub_logits[sid].numpy()
+        out[f"run_det_{sid}"] = det_probs[sid].numpy()
+        out[f"run_seg_{sid}"] = seg_probs[sid].numpy()
+    print(f"[wsi_callers] reference zero_shot_classifier / get_zeroshot_classifier / run x3 recorded ({len(out)} arrays)")
+    np.savez_compressed(os.path.join(GOLD, "wsi_callers.npz"), weight_seed=seed, feat_seed=77, cls3=cls3.numpy(),
+                        feats_checksum=float(sum(checksum(f) for f in feats.values())), **out)
+
+
 def import_reference_tile_eval():
     """training/path_training/zero_shot.py as shipped.  Its package imports (`path_open_clip`: timm/open_clip model
     code that does not import here) are replaced by a stub package that carries the REAL metric functions of
@@ -368,11 +429,13 @@ def golden_c3(n_tiles: int = 4096, chunk: int = 256, n_prompts: int = 64):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["wsi", "tile_eval", "bert2", "bert12", "vit2", "vit24", "vit24_bench"]
+    which = sys.argv[1:] or ["wsi", "wsi_callers", "tile_eval", "bert2", "bert12", "vit2", "vit24", "vit24_bench"]
     if "tile_eval" in which:
         golden_tile_eval()
     if "wsi" in which:
         golden_wsi()
+    if "wsi_callers" in which:
+        golden_wsi_callers()
     if "bert2" in which:
         golden_bert(2, 4, seed=11)
     if "bert12" in which:
