@@ -73,12 +73,12 @@ def main():
     coords224 = torch.stack([(idx % grid) * 224, (idx // grid) * 224], 1).numpy()
 
     t0 = time.perf_counter()
-    ens = wsi.zero_shot_prompt_select(model, classifiers, feats, min(args.topn, args.prompt_sets))
-    label = int(wsi.zero_shot_subtyping(model, ens, feats, coords256, 256, True))
-    ens2 = wsi.zero_shot_prompt_select(model, [c[:, :2].contiguous() for c in classifiers], feats, min(args.topn, args.prompt_sets))
-    ratio = wsi.zero_shot_detection(model, ens2, feats, coords256, 256, False)
+    ens = wsi.zero_shot_prompt_select(classifiers, feats, min(args.topn, args.prompt_sets), dev)
+    label = int(wsi.zero_shot_subtyping(ens, feats, coords256, 256, True))
+    ens2 = wsi.zero_shot_prompt_select([c[:, :2].contiguous() for c in classifiers], feats, min(args.topn, args.prompt_sets), dev)
+    ratio = wsi.zero_shot_detection(ens2, feats, coords256, 256, False)
     prob16 = model.similarity(torch.nn.functional.normalize(feats), ens2.t().contiguous(), scale=10.0, mode="softmax_f16")
-    seg = wsi.zero_shot_segment_probs(model, ens2, feats, coords224, 224, True)
+    seg = wsi.zero_shot_segment(ens2, feats, coords224, None, 224, True)
     torch.cuda.synchronize()
     t_slide = time.perf_counter() - t0
     if rank == 0:

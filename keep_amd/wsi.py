@@ -201,9 +201,9 @@ def cood2str(cood):
     return str(cood[0]) + "_" + str(cood[1])
 
 
-def str2cood(s):
+def str2cood(str):                      # noqa: A002 -- the reference's parameter name (utils.py:150)
     """utils.py:150-151."""
-    return [int(item) for item in s.split("_")]
+    return [int(item) for item in str.split("_")]
 
 
 def accuracy(logits, target, topk=(1,)):

@@ -32,6 +32,11 @@ def test_product_package_never_imports_oracle_or_reference():
             # the reference also delegates to that library -- and it must not touch any model class
             if os.path.basename(f) == "tokenizer.py":
                 assert "Model" not in src.replace("KEEPModel", ""), f
+            elif os.path.basename(f) == "hf.py":
+                # the Auto* registration shim (keep_inference.py:75-76): the registries and the config base class, never a model implementation
+                assert m in ("__future__", "transformers", "config", "model"), f"{f} imports {m}"
+                names = {a.name for n in ast.walk(ast.parse(src)) if isinstance(n, ast.ImportFrom) and n.module == "transformers" for a in n.names}
+                assert names == {"AutoConfig", "AutoModel", "PretrainedConfig"}, names
             else:
                 assert not m.startswith("transformers") and not m.startswith("timm"), f"{f} imports {m}"
 
@@ -47,7 +52,8 @@ def test_csrc_has_no_compat_layers():
 def test_required_files_exist():
     for rel in ("bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/keep_hip.h",
                 "oracle/keep_oracle.py", "tools/make_golden.py", "tests/golden/vit_d24.npz",
-                "tests/golden/bert_l12.npz", "tests/golden/wsi_logic.npz"):
+                "tests/golden/bert_l12.npz", "tests/golden/wsi_logic.npz", "tests/golden/wsi_callers.npz",
+                "tests/golden/reference_signatures.json"):
         assert os.path.exists(os.path.join(ROOT, rel)), rel
 
 

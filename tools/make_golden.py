@@ -273,6 +273,27 @@ def golden_wsi_callers(seed: int = 9):
                         feats_checksum=float(sum(checksum(f) for f in feats.values())), **out)
 
 
+def golden_signatures():
+    """The L4 call surface as the reference declares it (inspect.signature of the live functions) -> tests/golden/reference_signatures.json;
+    tests/test_reference_signatures.py holds keep_amd's functions to it."""
+    import inspect, json
+    mods = dict(zip(("utils", "subtyping_utils", "detection_utils", "segment_utils"), import_reference_wsi()))
+    want = {"utils": ["zero_shot_classifier", "get_zeroshot_classifier", "rank_cls_score", "zero_shot_prompt_select", "cood2str", "str2cood", "accuracy"],
+            "subtyping_utils": ["run", "refine_seg", "zero_shot_subtyping"],
+            "detection_utils": ["run", "refine_seg", "zero_shot_detection"],
+            "segment_utils": ["run", "zero_shot_segment", "refine_seg"]}
+    table = {}
+    for mod, names in want.items():
+        for n in names:
+            fn = getattr(mods[mod], n)
+            params = [[p.name] if p.default is inspect.Parameter.empty else [p.name, p.default]
+                      for p in inspect.signature(fn).parameters.values()]
+            table[f"{mod}.{n}"] = {"params": params, "line": f"WSI_evaluation/{mod}.py:{inspect.getsourcelines(fn)[1]}"}
+    with open(os.path.join(GOLD, "reference_signatures.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    print(f"[signatures] {len(table)} reference functions recorded")
+
+
 def import_reference_tile_eval():
     """training/path_training/zero_shot.py as shipped.  Its package imports (`path_open_clip`: timm/open_clip model
     code that does not import here) are replaced by a stub package that carries the REAL metric functions of
@@ -429,13 +450,15 @@ def golden_c3(n_tiles: int = 4096, chunk: int = 256, n_prompts: int = 64):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    which = sys.argv[1:] or ["wsi", "wsi_callers", "tile_eval", "bert2", "bert12", "vit2", "vit24", "vit24_bench"]
+    which = sys.argv[1:] or ["wsi", "wsi_callers", "signatures", "tile_eval", "bert2", "bert12", "vit2", "vit24", "vit24_bench"]
     if "tile_eval" in which:
         golden_tile_eval()
     if "wsi" in which:
         golden_wsi()
     if "wsi_callers" in which:
         golden_wsi_callers()
+    if "signatures" in which:
+        golden_signatures()
     if "bert2" in which:
         golden_bert(2, 4, seed=11)
     if "bert12" in which:

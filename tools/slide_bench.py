@@ -21,13 +21,13 @@ fn = t("normalize features [100k,768]", lambda: wsi._normalized(m, feats))
 bank = torch.stack([c.t() for c in cls]).reshape(K * C, D).contiguous()
 for mode, name in ((1, "fused, fp16 + MX-fp4 corrections, top-2 in registers"), (2, "fused, three fp16 passes"), (0, "unfused: fp32 MFMA GEMM, logits through HBM")):
     m.set_option("fused_screening", mode)
-    sc_m = t(f"prompt_scores [100k,768]x[768,{K*C}] (1.09 TFLOP): {name}", lambda: wsi.prompt_scores(m, fn, cls, pre_normalized=True), 3)
+    sc_m = t(f"prompt_scores [100k,768]x[768,{K*C}] (1.09 TFLOP): {name}", lambda: wsi.prompt_scores(fn, cls, pre_normalized=True, model=m), 3)
     if mode == 1: sc = sc_m
     else: print(f"    max |score - fused score| = {(sc_m - sc).abs().max().item():.2e}")
 m.set_option("fused_screening", 1)
-ens = t("zero_shot_prompt_select (scores + sort + merge top 50)", lambda: wsi.zero_shot_prompt_select(m, cls, feats, 50), 3)
+ens = t("zero_shot_prompt_select (scores + sort + merge top 50)", lambda: wsi.zero_shot_prompt_select(cls, feats, 50, "cuda:0", model=m), 3)
 pr = t("probabilities softmax(10 cos) [100k,4]", lambda: wsi._probs(m, ens, feats))
-t("refine (coordinate hash + 2x2 neighbour mean)", lambda: wsi.refine(m, pr, coords, 256, True))
-t("zero_shot_subtyping end to end (given classifier)", lambda: wsi.zero_shot_subtyping(m, ens, feats, coords, 256, True))
-t("zero_shot_detection end to end", lambda: wsi.zero_shot_detection(m, ens[:, :2].contiguous(), feats, coords, 256, False))
-t("zero_shot_segment_probs end to end (dict of 100k entries)", lambda: wsi.zero_shot_segment_probs(m, ens[:, :2].contiguous(), feats, coords, 224, True), 2)
+t("refine (coordinate hash + 2x2 neighbour mean)", lambda: wsi.refine(pr, coords, 256, True, model=m))
+t("zero_shot_subtyping end to end (given classifier)", lambda: wsi.zero_shot_subtyping(ens, feats, coords, 256, True, model=m))
+t("zero_shot_detection end to end", lambda: wsi.zero_shot_detection(ens[:, :2].contiguous(), feats, coords, 256, False, model=m))
+t("zero_shot_segment_probs end to end (dict of 100k entries)", lambda: wsi.zero_shot_segment_probs(ens[:, :2].contiguous(), feats, coords, 224, True, model=m), 2)
