@@ -121,42 +121,56 @@ def config3(model, dev):
     toks["token_type_ids"] = torch.zeros_like(toks["input_ids"])
     model.reserve(tiles=chunk, prompts=P, seq=256)
 
+    txt = model.encode_text(toks)
+
     def run():
-        feats = torch.cat([model.encode_image(tiles[i:i + chunk]) for i in range(0, n, chunk)])
-        txt = model.encode_text(toks)
-        return model.similarity(feats, txt, mode="argmax"), txt
+        # the default path of config 3: KEEPModel.classify = default-precision encode of every tile, similarity + argmax, and a second,
+        # split-product encode of the tiles whose top-2 margin is below the engine's label_margin (keep_classify in the C ABI)
+        return model.classify(tiles, txt, return_features=True)
 
     run()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    (sim, lab), txt = run()
+    txt = model.encode_text(toks)
+    sim, lab, feats = run()
     torch.cuda.synchronize(dev)
     t_all = time.perf_counter() - t0
+    rechecked = model.last_rechecked
+    t_cls = time_gpu(run, dev, 1)
     t_img = time_gpu(lambda: [model.encode_image(tiles[i:i + chunk]) for i in range(0, n, chunk)], dev, 1)
     t_txt = time_gpu(lambda: model.encode_text(toks), dev, 5)
-    feats = torch.cat([model.encode_image(tiles[i:i + chunk]) for i in range(0, n, chunk)])
-    t_sim = time_gpu(lambda: model.similarity(feats, txt, mode="argmax"), dev, 20)
+    plain = torch.cat([model.encode_image(tiles[i:i + chunk]) for i in range(0, n, chunk)])
+    psim, plab = model.similarity(plain, txt, mode="argmax")             # what the labels would be without the second look
+    t_sim = time_gpu(lambda: model.similarity(plain, txt, mode="argmax"), dev, 20)
     ref = torch.from_numpy(g["sims"]).to(dev)
     ref_lab = torch.from_numpy(g["argmax"].astype("int64")).to(dev)
     margin = torch.from_numpy(g["margin"]).to(dev)
     d = (sim - ref).abs()
-    d_img = (feats @ torch.from_numpy(g["txt"]).to(dev).t() - ref).abs()            # image-tower share: GPU tiles x oracle text features
+    dp = (psim - ref).abs()
+    d_img = (plain @ torch.from_numpy(g["txt"]).to(dev).t() - ref).abs()            # image-tower share: GPU tiles x oracle text features
     same = lab.long() == ref_lab
+    psame = plab.long() == ref_lab
     near = margin < 2e-4                                                            # tiles whose two best prompts are closer than 2 x tolerance
-    parity = {"max_abs_dcos": float(f"{d.max().item():.3e}"), "rms_dcos": float(f"{d.pow(2).mean().sqrt().item():.3e}"),
-              "n_cosines": int(d.numel()), "sim_match_rate_1e-4": round(float((d <= 1e-4).float().mean().item()), 6),
+    parity = {"max_abs_dcos": float(f"{max(d.max().item(), dp.max().item()):.3e}"), "rms_dcos": float(f"{dp.pow(2).mean().sqrt().item():.3e}"),
+              "n_cosines": int(d.numel()), "sim_match_rate_1e-4": round(float(((d <= 1e-4) & (dp <= 1e-4)).float().mean().item()), 6),
               "argmax_match_rate": round(float(same.float().mean().item()), 6),
-              "argmax_mismatches": int((~same).sum().item()),
-              "max_margin_of_a_mismatch": float(f"{(margin[~same].max().item() if (~same).any() else 0.0):.3e}"),
+              "argmax_mismatches": int((~same).sum().item()), "labels_bit_exact": bool(same.all().item()),
+              "labels_from": "KEEPModel.classify (keep_classify): default-precision encode + split-product second look at tiles with a top-2 margin "
+                             f"< label_margin = {model.get_option('label_margin'):.2e}",
+              "tiles_encoded_twice": int(rechecked), "tiles": n,
+              "without_second_look": {"argmax_mismatches": int((~psame).sum().item()),
+                                      "max_margin_of_a_mismatch": float(f"{(margin[~psame].max().item() if (~psame).any() else 0.0):.3e}")},
               "near_tie_tiles": int(near.sum().item()), "near_tie_argmax_match": int((same & near).sum().item()),
+              "smallest_oracle_margin": float(f"{margin.min().item():.3e}"),
               "image_tower_only_max_abs_dcos": float(f"{d_img.max().item():.3e}"),
               "north_star_tolerance": 1e-4, "precision_mode": model.precision_name,
               "reference": "tests/golden/c3_dual_tower.npz: fp32 CPU oracle on BASELINE config 3 (4096 tiles x 64 prompts, both towers, "
-                           "seed-0 weights); a label can only differ where the oracle's own top-2 margin is below the cosine error"}
+                           "seed-0 weights); max / rms / match-rate cover BOTH the first-pass cosines and the returned ones"}
     exec_T = model.last_text_length
     bytes_sim = 4 * (768 * n + 768 * P + n * P)
     cfg = {"workload": "config 3: 4096 tiles (16 x 256, fp32 pixels) + 64 prompts x 256 tokens -> sim [4096,64] fp32 + argmax, 1 GPU",
-           "seconds": round(t_all, 4), "tiles_per_s": round(n / t_img, 1),
+           "seconds": round(t_all, 4), "tiles_per_s": round(n / t_cls, 1), "tiles_per_s_without_second_look": round(n / t_img, 1),
+           "second_look_cost": round(t_cls / t_img - 1.0, 4),
            "prompts_per_s_padded_equivalent": round(P / t_txt, 1),
            "text_tflops_padded_equivalent": round(P * BERT_FLOPS_PER_PROMPT_256 / t_txt / 1e12, 1),
            "text_executed_length": int(exec_T), "text_ms": round(t_txt * 1e3, 3),
@@ -297,6 +311,8 @@ def main():
         log("config 3 (4096 tiles x 64 prompts, parity vs the oracle fixture) ...")
         c3, parity = config3(model, dev)
         c5 = config5(model, dev)
+        if parity is not None and not parity["labels_bit_exact"]:
+            log(f"WARNING: {parity['argmax_mismatches']} config-3 labels differ from the fp32 oracle's -- the north star asks for bit-exact labels")
         log("configs done")
 
     line = None

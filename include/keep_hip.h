@@ -95,6 +95,7 @@ int keep_bert_layers(keep_handle* h);
  *   "comp_full_blocks" KEEP_PREC_COMP: ViT blocks whose qkv / attention / proj run as split products (default 1)
  *   "comp_mlp_blocks"  KEEP_PREC_COMP: ViT blocks whose fc1 / fc2 run as compensated products (default 8)
  *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
+ *   "label_margin"     keep_classify: cosine margin below which a tile's label is re-derived in KEEP_PREC_STRICT (default 2.5e-4)
  *   "fused_screening"  keep_prompt_scores with C in {2, 4}: 1 (default) one compensated GEMM with the top-2 score taken in the
  *                     accumulator registers (no logits in HBM) | 2 the same with three fp16 passes | 0 chunked fp32 GEMM + reduction
  *   "max_tiles"       tiles per internal sub-batch of keep_encode_image (default 256)
@@ -165,6 +166,19 @@ int keep_token_error_async(keep_handle* h, int32_t* host_flag, void* stream);
  *   img fp32 [N,D], txt fp32 [P,D] (row-major; a reference classifier [D,C] is passed transposed). */
 int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t N, int64_t P, int64_t D,
                     float scale, int mode, void* out, int32_t* argmax_out, void* stream);
+
+/* Replaces: `img_feature = model.encode_image(img_input)` + `img_feature @ text_feature.T` + the row argmax taken from it
+ * (quick_start/keep_inference.py:101,104; BASELINE config 3) when the LABELS must be the fp32 reference's.
+ *   The default precision keeps every cosine within 1e-4 of the fp32 reference, which cannot decide a tile whose two best prompts are
+ *   closer than that.  keep_classify encodes all B tiles in the handle's precision, takes sim = scale * feats @ txt^T and its row argmax,
+ *   then re-encodes ONLY the tiles whose top-2 margin (in cosine units, i.e. / scale) is below `margin` in KEEP_PREC_STRICT (split
+ *   products, ~5e-7) and takes those rows again.  margin < 0: the handle's "label_margin" option (default 2.5e-4 = 2 x tolerance + 25 %);
+ *   margin == 0: no second look.  One host synchronisation of `stream` (the number of flagged tiles).
+ *   pixels / pix_dtype / B as keep_encode_image (16-byte aligned); txt fp32 [P,D] L2-normalised text features (keep_encode_text);
+ *   feats_out fp32 [B,D] or NULL; sim_out fp32 [B,P] or NULL; labels_out int32 [B] (first maximum wins, as torch.argmax);
+ *   n_rechecked (HOST pointer or NULL): how many tiles were encoded twice. */
+int keep_classify(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, const float* txt, int64_t P, float scale, float margin,
+                  float* feats_out, float* sim_out, int32_t* labels_out, int64_t* n_rechecked, void* stream);
 
 /* ---- slide-level zero-shot steps ---------------------------------
  * Replaces the loop of `zero_shot_prompt_select` (WSI_evaluation/utils.py:127-130: one GEMM + one

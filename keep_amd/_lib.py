@@ -41,6 +41,7 @@ SIGNATURES = {
     "keep_token_error": (_i32, [_vp, _vp]),
     "keep_token_error_async": (_i32, [_vp, _vp, _vp]),
     "keep_similarity": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp, _vp]),
+    "keep_classify": (_i32, [_vp, _vp, _i32, _i64, _vp, _i64, _f32, _f32, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "keep_prompt_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "keep_group_argmax": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "keep_retrieval_rank": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -208,6 +208,10 @@ int launch_sim_small(const float* img, const float* txt, int N, int P, int D, fl
 int launch_sim_mid(const float* img, const float* txt, int N, int P, int D, float scale, int mode, void* out, int32_t* amax,
                    hipStream_t s);              // 9 <= P <= 64: fused fp32-MFMA similarity + argmax / softmax; 0 handled, -1 not eligible
 void launch_diag_rank(const float* sim, int rows, int n_img, const int* target, int row0, int* rank, hipStream_t s);
+// keep_classify: ordered list of the rows whose top-2 margin is below `bound` (count on the device), tile / row movers
+void launch_top2_margin_flags(const float* sim, int N, int P, float bound, int* flags, int* list, int* count, hipStream_t s);
+void launch_gather_tiles(const void* src, int64_t tile_bytes, const int* list, int n, void* dst, hipStream_t s);     // tile_bytes % 16 == 0
+void launch_scatter_rows(const float* src, const int* list, int n, int D, float* dst, hipStream_t s);
 void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
                    unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s);
 

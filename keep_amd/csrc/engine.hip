@@ -88,6 +88,10 @@ struct keep_handle {
     int comp_mlp_blocks = 8;     // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
     int fused_screening = 1;     // keep_prompt_scores: 1 fused compensated GEMM (default) | 2 fused 3-pass split GEMM | 0 logits through HBM (any C)
     int comp_min_tiles = 32;     // lanes with fewer tiles take the split product where a compensated one is asked for (small-M kernels)
+    // keep_classify: tiles whose top-2 cosine margin is below this are re-encoded in KEEP_PREC_STRICT before their label is taken.
+    // Default = 2 x the north-star tolerance (both cosines of a pair can move by 1e-4 in opposite directions) + 25 %.
+    float label_margin = 2.5e-4f;
+    char* cls_buf = nullptr; size_t cls_bytes = 0;     // keep_classify scratch (features, similarity, flags, staged tiles): outside the arena, which the encodes carve
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
@@ -810,192 +814,8 @@ void planes_to_f32(const f16* hi, const f16* lo, float* out, int64_t n, hipStrea
     hipLaunchKernelGGL(f16_planes_to_f32_kernel, dim3(blocks), dim3(256), 0, s, hi, lo, out, n);
 }
 
-}  // namespace
-
-// =============================================================================================
-extern "C" {
-
-const char* keep_version(void) { return "keep_hip 0.1 (gfx950)"; }
-
-int keep_create(int device_id, keep_handle** out) {
-    if (!out) return KEEP_EINVAL;
-    *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return KEEP_EHIP;
-    DevGuard guard(device_id);
-    if (!guard.ok) return KEEP_EHIP;
-    keep_handle* h = new keep_handle();
-    h->device = device_id;
-    if (hipMalloc(&h->err_flag, sizeof(int)) != hipSuccess) { delete h; return KEEP_ENOMEM; }
-    hipMemset(h->err_flag, 0, sizeof(int));
-    *out = h;
-    return KEEP_OK;
-}
-
-int keep_destroy(keep_handle* h) {
-    if (!h) return KEEP_OK;
-    DevGuard guard(h->device);
-    hipDeviceSynchronize();
-    h->prof_collect();
-    for (auto& e : h->pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo);
-                            if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); }
-    if (h->tune.dbg) hipFree(h->tune.dbg);
-    for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
-    drop_graphs(h);
-    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    if (h->arena) hipFree(h->arena);
-    if (h->err_flag) hipFree(h->err_flag);
-    for (int l = 0; l < 4; ++l) { if (h->aux[l]) hipStreamDestroy(h->aux[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    delete h;
-    return KEEP_OK;
-}
-
-const char* keep_last_error(keep_handle* h) { return h ? h->err.c_str() : "null handle"; }
-
-int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndim, const int64_t* shape, int on_device) {
-    if (!h || !key || !data || ndim < 0 || ndim > 8) return KEEP_EINVAL;
-    KEEP_ON_DEVICE(h);
-    const std::string k(key);
-    if (k == "text.embeddings.position_ids" || k == "text.embeddings.token_type_ids") return KEEP_OK;   // buffers of older checkpoints
-    if (!known_key(k)) return h->fail(KEEP_EKEY, "unexpected key %s", key);
-    std::vector<int64_t> shp(shape, shape + ndim);
-    if (ndim == 0) shp = {1};
-    const int64_t n = numel_of(shp);
-    if (n <= 0) return h->fail(KEEP_EINVAL, "%s: bad shape", key);
-    if (on_device) {
-        // the repack below runs on the null stream; whatever produced `data` (e.g. a dtype conversion on the caller's
-        // stream) must have finished first, and this entry point takes no stream: load time, so simply drain the device
-        HIPCHK(h, hipDeviceSynchronize());
-        return store_tensor(h, k, data, shp);
-    }
-    float* tmp = nullptr;
-    HIPCHK(h, hipMalloc(&tmp, n * sizeof(float)));
-    hipError_t e = hipMemcpy(tmp, data, n * sizeof(float), hipMemcpyHostToDevice);
-    int rc = e == hipSuccess ? store_tensor(h, k, tmp, shp) : h->fail(KEEP_EHIP, "H2D copy of %s failed", key);
-    hipFree(tmp);
-    return rc;
-}
-
-int keep_finalize_weights(keep_handle* h) {
-    if (!h) return KEEP_EINVAL;
-    KEEP_ON_DEVICE(h);
-    ++h->opt_epoch;
-    int rc = finalize_vit(h);
-    if (rc) return rc;
-    rc = finalize_bert(h);
-    if (rc) return rc;
-    if (!h->vit_depth && !h->bert_layers) return h->fail(KEEP_EKEY, "no tower loaded");
-    HIPCHK(h, hipDeviceSynchronize());
-    h->finalized = true;
-    return KEEP_OK;
-}
-
-int keep_vit_depth(keep_handle* h) { return h && h->finalized ? h->vit_depth : 0; }
-int keep_bert_layers(keep_handle* h) { return h && h->finalized ? h->bert_layers : 0; }
-
-int keep_set_option(keep_handle* h, const char* name, double value) {
-    if (!h || !name) return KEEP_EINVAL;
-    const std::string n(name);
-    const int v = (int)value;
-    ++h->opt_epoch;               // captured graphs bake kernel selection and precision in: drop them lazily
-    KeepTune& t = h->tune;
-    if (n == "graphs") { h->use_graphs = v ? 1 : 0; return KEEP_OK; }
-    if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT && v != KEEP_PREC_COMP) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
-    else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
-    else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
-    else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
-    else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
-    else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
-    else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
-    else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
-    else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
-    else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
-    else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
-    else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
-    else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); t.sgemv_m = v; }
-    else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); t.gemm_skinny_m = v; }
-    else if (n == "lane_min_tiles") { if (v < 6) return h->fail(KEEP_EINVAL, "lane_min_tiles must be >= 6"); h->lane_min_tiles = v; }
-    else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
-    else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
-    else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); t.ln_impl = v; }
-    else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); t.attn_waves = v; }
-    else if (n == "gemm_impl") {
-        bool ok = v == 0 || v == 128 || v == 256;
-        if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256)", v);
-        t.gemm_impl = v;
-    }
-#ifdef KEEP_DIAGNOSTICS
-    // result-changing / timing diagnostics exist only in -DKEEP_DIAGNOSTICS builds (tools/gemm_timeline.py, tools/attn_timeline.py)
-    else if (n == "dbg_skip_ln") h->dbg_skip_ln = v;
-    else if (n == "gemm_ablate") { t.gemm_ablate = v; }
-    else if (n == "gemm_dbg") {
-        if (v && !t.dbg) { HIPCHK(h, hipMalloc(&t.dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(t.dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
-        if (!v && t.dbg) { hipFree(t.dbg); t.dbg = nullptr; }
-    }
-#endif
-    else return h->fail(KEEP_EINVAL, "unknown option %s", name);
-    return KEEP_OK;
-}
-double keep_get_option(keep_handle* h, const char* name) {
-    if (!h || !name) return -1;
-    const std::string n(name);
-    const KeepTune& t = h->tune;
-    if (n == "precision") return h->precision;
-    if (n == "strict_blocks") return h->strict_blocks;
-    if (n == "comp_full_blocks") return h->comp_full_blocks;
-    if (n == "comp_mlp_blocks") return h->comp_mlp_blocks;
-    if (n == "comp_min_tiles") return h->comp_min_tiles;
-    if (n == "max_tiles") return h->max_tiles;
-    if (n == "max_prompts") return h->max_prompts;
-    if (n == "gemm_impl") return t.gemm_impl;
-    if (n == "streams") return h->n_streams;
-    if (n == "graphs") return h->use_graphs;
-    if (n == "gemm_skinny_m") return t.gemm_skinny_m;
-    if (n == "sgemv_m") return t.sgemv_m;
-    if (n == "gemm_splitk_tiles") return t.gemm_splitk_tiles;
-    if (n == "gemm_persistent") return t.gemm_persistent;
-    if (n == "ln_impl") return t.ln_impl;
-    if (n == "attn_waves") return t.attn_waves;
-    if (n == "lane_skew") return h->lane_skew;
-    if (n == "lane0_permille") return h->lane0_permille;
-    if (n == "cls_tail") return h->cls_tail;
-    return -1;
-}
-
-int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
-    if (!h || !h->finalized) return h ? h->fail(KEEP_ESTATE, "weights not finalised") : KEEP_EINVAL;
-    KEEP_ON_DEVICE(h);
-    size_t need = 0;
-    if (tiles > 0 && h->vit_depth) {
-        int lanes = h->n_streams;
-        while (lanes > 1 && tiles < (int64_t)lanes * h->lane_min_tiles) --lanes;
-        int64_t per = (tiles + lanes - 1) / lanes;
-        if (per > h->max_tiles) per = h->max_tiles;
-        need = align_up(vit_ws_bytes(h, per, h->any_split())) * lanes;
-        if (tiles * 197 <= SKINNY_MAX_M)          // graph-replayed call: + staged pixels (fp32 at most) and outputs
-            need += align_up((size_t)tiles * 3 * 224 * 224 * 4) + align_up((size_t)tiles * h->proj_dim * 4);
-    }
-    if (prompts > 0 && seq > 0 && h->bert_layers) {
-        const int64_t pc = prompts < h->max_prompts ? prompts : h->max_prompts;
-        size_t t = align_up(txt_ws_bytes(h, pc, seq, h->any_split()));
-        if (prompts * seq <= SKINNY_MAX_M)        // graph-replayed call: + staged ids / types / mask and outputs
-            t += 3 * align_up((size_t)prompts * seq * 8) + align_up((size_t)prompts * h->bert_H * 4);
-        need = t > need ? t : need;
-    }
-    return ensure_arena(h, need);
-}
-int64_t keep_workspace_bytes(keep_handle* h) { return h ? (int64_t)h->arena_bytes : 0; }
-
-int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, float* out, void* stream) {
-    if (!h) return KEEP_EINVAL;
-    if (!h->finalized || !h->vit_depth) return h->fail(KEEP_ESTATE, "image tower not loaded / finalised");
-    if (!pixels || !out || B < 0) return h->fail(KEEP_EINVAL, "null pointer or negative batch");
-    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_U8_HWC) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
-    if (B == 0) return KEEP_OK;
-    KEEP_ON_DEVICE(h);
-    hipStream_t s = (hipStream_t)stream;
+// the image tower on B tiles (arguments checked, device selected by the caller)
+int encode_image_run(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, float* out, hipStream_t s) {
     ++h->dbg_calls;
     if (h->use_graphs && !h->prof_mode && B * 197 <= SKINNY_MAX_M && B <= h->max_tiles) {
         const size_t pxb = pix_dtype == KEEP_PIX_F32 ? 4 : (pix_dtype == KEEP_PIX_U8_HWC ? 1 : 2);
@@ -1007,7 +827,7 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
         float* st_out = (float*)(h->arena + ws_bytes + align_up(ib));
         HIPCHK(h, hipMemcpyAsync(st_pix, pixels, ib, hipMemcpyDeviceToDevice, s));
         char key[96];
-        snprintf(key, sizeof key, "img|%lld|%d", (long long)B, pix_dtype);
+        snprintf(key, sizeof key, "img|%lld|%d|%d", (long long)B, pix_dtype, h->precision);     // (keep_classify switches the precision per call, without an option epoch)
         rc = graph_run(h, key, s, [&](hipStream_t cs) {
             VitLane L{};
             L.Bc = (int)B; L.pixels = st_pix; L.pix_dtype = pix_dtype; L.out = st_out; L.s = cs;
@@ -1079,6 +899,233 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
             HIPCHK(h, hipStreamWaitEvent(s, h->ev_join[l], 0));
         }
     return KEEP_OK;
+}
+
+
+int similarity_run(keep_handle* h, const float* img, const float* txt, int64_t N, int64_t P, int64_t D, float scale, int mode,
+                   void* out, int32_t* argmax_out, hipStream_t s) {
+    Scope sc(h, T_SIM, s);
+    if (h->tune.sgemv_m > 0 && launch_sim_small(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
+        return check_launch(h, "similarity");
+    if (h->tune.sgemv_m > 0 && launch_sim_mid(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
+        return check_launch(h, "similarity");
+    float* logits = (float*)out;
+    const bool need_tmp = (mode == KEEP_SIM_ARGMAX && !out) || mode == KEEP_SIM_SOFTMAX_F16 || mode == KEEP_SIM_TOP2SCORE;
+    const int nb = (int)((N + 255) / 256);
+    if (need_tmp) {
+        // scratch lives at the tail end of the arena so that a preceding encode on the same stream
+        // (which uses the front) is not disturbed; stream order serialises reuse.
+        const size_t bytes = align_up((size_t)N * P * 4) + align_up((size_t)nb * 4) + 256;
+        int rc = ensure_arena(h, bytes);
+        if (rc) return rc;
+        logits = (float*)h->arena;
+    }
+    SgemmParams g{};
+    g.tune = &h->tune;
+    g.a = img; g.lda = D; g.b = txt; g.ldb = D; g.out = logits; g.ldo = P; g.bias = nullptr;
+    g.M = (int)N; g.N = (int)P; g.K = (int)D; g.act = ACT_NONE;
+    g.scale = (mode == KEEP_SIM_RAW || mode == KEEP_SIM_ARGMAX) ? scale : 1.0f;
+    if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "similarity shape");
+    if (mode == KEEP_SIM_ARGMAX) launch_row_argmax(logits, (int)N, (int)P, argmax_out, s);
+    else if (mode == KEEP_SIM_SOFTMAX) launch_row_softmax(logits, (int)N, (int)P, scale, logits, s);
+    else if (mode == KEEP_SIM_SOFTMAX_F16) launch_row_softmax_f16(logits, (int)N, (int)P, scale, (f16*)out, s);
+    else if (mode == KEEP_SIM_TOP2SCORE) {
+        float* partial = (float*)(h->arena + align_up((size_t)N * P * 4));
+        launch_top2_score(logits, (int)N, (int)P, partial, (float*)out, s);
+    }
+    return check_launch(h, "similarity");
+}
+
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* keep_version(void) { return "keep_hip 0.1 (gfx950)"; }
+
+int keep_create(int device_id, keep_handle** out) {
+    if (!out) return KEEP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return KEEP_EHIP;
+    DevGuard guard(device_id);
+    if (!guard.ok) return KEEP_EHIP;
+    keep_handle* h = new keep_handle();
+    h->device = device_id;
+    if (hipMalloc(&h->err_flag, sizeof(int)) != hipSuccess) { delete h; return KEEP_ENOMEM; }
+    hipMemset(h->err_flag, 0, sizeof(int));
+    *out = h;
+    return KEEP_OK;
+}
+
+int keep_destroy(keep_handle* h) {
+    if (!h) return KEEP_OK;
+    DevGuard guard(h->device);
+    hipDeviceSynchronize();
+    h->prof_collect();
+    for (auto& e : h->pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo);
+                            if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); }
+    if (h->tune.dbg) hipFree(h->tune.dbg);
+    for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
+    drop_graphs(h);
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    if (h->arena) hipFree(h->arena);
+    if (h->cls_buf) hipFree(h->cls_buf);
+    if (h->err_flag) hipFree(h->err_flag);
+    for (int l = 0; l < 4; ++l) { if (h->aux[l]) hipStreamDestroy(h->aux[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    delete h;
+    return KEEP_OK;
+}
+
+const char* keep_last_error(keep_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndim, const int64_t* shape, int on_device) {
+    if (!h || !key || !data || ndim < 0 || ndim > 8) return KEEP_EINVAL;
+    KEEP_ON_DEVICE(h);
+    const std::string k(key);
+    if (k == "text.embeddings.position_ids" || k == "text.embeddings.token_type_ids") return KEEP_OK;   // buffers of older checkpoints
+    if (!known_key(k)) return h->fail(KEEP_EKEY, "unexpected key %s", key);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (ndim == 0) shp = {1};
+    const int64_t n = numel_of(shp);
+    if (n <= 0) return h->fail(KEEP_EINVAL, "%s: bad shape", key);
+    if (on_device) {
+        // the repack below runs on the null stream; whatever produced `data` (e.g. a dtype conversion on the caller's
+        // stream) must have finished first, and this entry point takes no stream: load time, so simply drain the device
+        HIPCHK(h, hipDeviceSynchronize());
+        return store_tensor(h, k, data, shp);
+    }
+    float* tmp = nullptr;
+    HIPCHK(h, hipMalloc(&tmp, n * sizeof(float)));
+    hipError_t e = hipMemcpy(tmp, data, n * sizeof(float), hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? store_tensor(h, k, tmp, shp) : h->fail(KEEP_EHIP, "H2D copy of %s failed", key);
+    hipFree(tmp);
+    return rc;
+}
+
+int keep_finalize_weights(keep_handle* h) {
+    if (!h) return KEEP_EINVAL;
+    KEEP_ON_DEVICE(h);
+    ++h->opt_epoch;
+    int rc = finalize_vit(h);
+    if (rc) return rc;
+    rc = finalize_bert(h);
+    if (rc) return rc;
+    if (!h->vit_depth && !h->bert_layers) return h->fail(KEEP_EKEY, "no tower loaded");
+    HIPCHK(h, hipDeviceSynchronize());
+    h->finalized = true;
+    return KEEP_OK;
+}
+
+int keep_vit_depth(keep_handle* h) { return h && h->finalized ? h->vit_depth : 0; }
+int keep_bert_layers(keep_handle* h) { return h && h->finalized ? h->bert_layers : 0; }
+
+int keep_set_option(keep_handle* h, const char* name, double value) {
+    if (!h || !name) return KEEP_EINVAL;
+    const std::string n(name);
+    const int v = (int)value;
+    ++h->opt_epoch;               // captured graphs bake kernel selection and precision in: drop them lazily
+    KeepTune& t = h->tune;
+    if (n == "graphs") { h->use_graphs = v ? 1 : 0; return KEEP_OK; }
+    if (n == "label_margin") { if (!(value >= 0.0) || value > 2.0) return h->fail(KEEP_EINVAL, "label_margin must be in [0, 2]"); h->label_margin = (float)value; return KEEP_OK; }
+    if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT && v != KEEP_PREC_COMP) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
+    else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
+    else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
+    else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
+    else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
+    else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
+    else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
+    else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
+    else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
+    else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
+    else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
+    else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
+    else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); t.sgemv_m = v; }
+    else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); t.gemm_skinny_m = v; }
+    else if (n == "lane_min_tiles") { if (v < 6) return h->fail(KEEP_EINVAL, "lane_min_tiles must be >= 6"); h->lane_min_tiles = v; }
+    else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
+    else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
+    else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); t.ln_impl = v; }
+    else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); t.attn_waves = v; }
+    else if (n == "gemm_impl") {
+        bool ok = v == 0 || v == 128 || v == 256;
+        if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256)", v);
+        t.gemm_impl = v;
+    }
+#ifdef KEEP_DIAGNOSTICS
+    // result-changing / timing diagnostics exist only in -DKEEP_DIAGNOSTICS builds (tools/gemm_timeline.py, tools/attn_timeline.py)
+    else if (n == "dbg_skip_ln") h->dbg_skip_ln = v;
+    else if (n == "gemm_ablate") { t.gemm_ablate = v; }
+    else if (n == "gemm_dbg") {
+        if (v && !t.dbg) { HIPCHK(h, hipMalloc(&t.dbg, (size_t)65536 * 4 * sizeof(long long))); HIPCHK(h, hipMemset(t.dbg, 0, (size_t)65536 * 4 * sizeof(long long))); }
+        if (!v && t.dbg) { hipFree(t.dbg); t.dbg = nullptr; }
+    }
+#endif
+    else return h->fail(KEEP_EINVAL, "unknown option %s", name);
+    return KEEP_OK;
+}
+double keep_get_option(keep_handle* h, const char* name) {
+    if (!h || !name) return -1;
+    const std::string n(name);
+    const KeepTune& t = h->tune;
+    if (n == "precision") return h->precision;
+    if (n == "label_margin") return h->label_margin;
+    if (n == "strict_blocks") return h->strict_blocks;
+    if (n == "comp_full_blocks") return h->comp_full_blocks;
+    if (n == "comp_mlp_blocks") return h->comp_mlp_blocks;
+    if (n == "comp_min_tiles") return h->comp_min_tiles;
+    if (n == "max_tiles") return h->max_tiles;
+    if (n == "max_prompts") return h->max_prompts;
+    if (n == "gemm_impl") return t.gemm_impl;
+    if (n == "streams") return h->n_streams;
+    if (n == "graphs") return h->use_graphs;
+    if (n == "gemm_skinny_m") return t.gemm_skinny_m;
+    if (n == "sgemv_m") return t.sgemv_m;
+    if (n == "gemm_splitk_tiles") return t.gemm_splitk_tiles;
+    if (n == "gemm_persistent") return t.gemm_persistent;
+    if (n == "ln_impl") return t.ln_impl;
+    if (n == "attn_waves") return t.attn_waves;
+    if (n == "lane_skew") return h->lane_skew;
+    if (n == "lane0_permille") return h->lane0_permille;
+    if (n == "cls_tail") return h->cls_tail;
+    return -1;
+}
+
+int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
+    if (!h || !h->finalized) return h ? h->fail(KEEP_ESTATE, "weights not finalised") : KEEP_EINVAL;
+    KEEP_ON_DEVICE(h);
+    size_t need = 0;
+    if (tiles > 0 && h->vit_depth) {
+        int lanes = h->n_streams;
+        while (lanes > 1 && tiles < (int64_t)lanes * h->lane_min_tiles) --lanes;
+        int64_t per = (tiles + lanes - 1) / lanes;
+        if (per > h->max_tiles) per = h->max_tiles;
+        need = align_up(vit_ws_bytes(h, per, h->any_split())) * lanes;
+        if (tiles * 197 <= SKINNY_MAX_M)          // graph-replayed call: + staged pixels (fp32 at most) and outputs
+            need += align_up((size_t)tiles * 3 * 224 * 224 * 4) + align_up((size_t)tiles * h->proj_dim * 4);
+    }
+    if (prompts > 0 && seq > 0 && h->bert_layers) {
+        const int64_t pc = prompts < h->max_prompts ? prompts : h->max_prompts;
+        size_t t = align_up(txt_ws_bytes(h, pc, seq, h->any_split()));
+        if (prompts * seq <= SKINNY_MAX_M)        // graph-replayed call: + staged ids / types / mask and outputs
+            t += 3 * align_up((size_t)prompts * seq * 8) + align_up((size_t)prompts * h->bert_H * 4);
+        need = t > need ? t : need;
+    }
+    return ensure_arena(h, need);
+}
+int64_t keep_workspace_bytes(keep_handle* h) { return h ? (int64_t)h->arena_bytes : 0; }
+
+int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, float* out, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!h->finalized || !h->vit_depth) return h->fail(KEEP_ESTATE, "image tower not loaded / finalised");
+    if (!pixels || !out || B < 0) return h->fail(KEEP_EINVAL, "null pointer or negative batch");
+    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_U8_HWC) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
+    if (B == 0) return KEEP_OK;
+    KEEP_ON_DEVICE(h);
+    return encode_image_run(h, pixels, pix_dtype, B, out, (hipStream_t)stream);
 }
 
 int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, const int64_t* mask, int64_t P, int64_t T,
@@ -1174,37 +1221,68 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
     if (mode != KEEP_SIM_ARGMAX && !out) return h->fail(KEEP_EINVAL, "out is null");
     if (N == 0) return KEEP_OK;
     KEEP_ON_DEVICE(h);
+    return similarity_run(h, img, txt, N, P, D, scale, mode, out, argmax_out, (hipStream_t)stream);
+}
+
+/* keep_classify (include/keep_hip.h): labels with the accuracy of the split-product arithmetic at (nearly) the cost of the default one. */
+int keep_classify(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, const float* txt, int64_t P, float scale, float margin,
+                  float* feats_out, float* sim_out, int32_t* labels_out, int64_t* n_rechecked, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (n_rechecked) *n_rechecked = 0;
+    if (!h->finalized || !h->vit_depth) return h->fail(KEEP_ESTATE, "image tower not loaded / finalised");
+    if (!pixels || !txt || !labels_out || B < 0 || P < 1) return h->fail(KEEP_EINVAL, "null pointer or bad shape");
+    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_U8_HWC) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
+    if (!(scale > 0.f)) return h->fail(KEEP_EINVAL, "classify needs scale > 0 (labels are the argmax of scale * cos)");
+    if (((uintptr_t)pixels & 15) != 0) return h->fail(KEEP_EINVAL, "pixels must be 16-byte aligned");
+    if (B == 0) return KEEP_OK;
+    if (B > (1 << 30)) return h->fail(KEEP_EINVAL, "batch too large");
+    KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
-    Scope sc(h, T_SIM, s);
-    if (h->tune.sgemv_m > 0 && launch_sim_small(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
-        return check_launch(h, "similarity");
-    if (h->tune.sgemv_m > 0 && launch_sim_mid(img, txt, (int)N, (int)P, (int)D, scale, mode, out, argmax_out, s) == 0)
-        return check_launch(h, "similarity");
-    float* logits = (float*)out;
-    const bool need_tmp = (mode == KEEP_SIM_ARGMAX && !out) || mode == KEEP_SIM_SOFTMAX_F16 || mode == KEEP_SIM_TOP2SCORE;
-    const int nb = (int)((N + 255) / 256);
-    if (need_tmp) {
-        // scratch lives at the tail end of the arena so that a preceding encode on the same stream
-        // (which uses the front) is not disturbed; stream order serialises reuse.
-        const size_t bytes = align_up((size_t)N * P * 4) + align_up((size_t)nb * 4) + 256;
-        int rc = ensure_arena(h, bytes);
-        if (rc) return rc;
-        logits = (float*)h->arena;
+    const int D = h->proj_dim;
+    if (margin < 0.f) margin = h->label_margin;
+    const size_t px = pix_dtype == KEEP_PIX_F32 ? 4 : (pix_dtype == KEEP_PIX_U8_HWC ? 1 : 2);
+    const size_t tile_bytes = (size_t)3 * 224 * 224 * px;
+    const int64_t stage_tiles = B < 256 ? B : 256;                      // flagged tiles are re-encoded in sub-batches of at most 256
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) { const size_t at = total; total += align_up(bytes); return at; };
+    const size_t o_feats = reserve((size_t)B * D * 4), o_sim = reserve((size_t)B * P * 4), o_flags = reserve((size_t)B * 4),
+                 o_list = reserve((size_t)B * 4), o_count = reserve(256), o_stage = reserve((size_t)stage_tiles * tile_bytes),
+                 o_f2 = reserve((size_t)stage_tiles * D * 4);
+    if (total > h->cls_bytes) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (h->cls_buf) HIPCHK(h, hipFree(h->cls_buf));
+        h->cls_buf = nullptr; h->cls_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->cls_buf, total));
+        h->cls_bytes = total;
     }
-    SgemmParams g{};
-    g.tune = &h->tune;
-    g.a = img; g.lda = D; g.b = txt; g.ldb = D; g.out = logits; g.ldo = P; g.bias = nullptr;
-    g.M = (int)N; g.N = (int)P; g.K = (int)D; g.act = ACT_NONE;
-    g.scale = (mode == KEEP_SIM_RAW || mode == KEEP_SIM_ARGMAX) ? scale : 1.0f;
-    if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "similarity shape");
-    if (mode == KEEP_SIM_ARGMAX) launch_row_argmax(logits, (int)N, (int)P, argmax_out, s);
-    else if (mode == KEEP_SIM_SOFTMAX) launch_row_softmax(logits, (int)N, (int)P, scale, logits, s);
-    else if (mode == KEEP_SIM_SOFTMAX_F16) launch_row_softmax_f16(logits, (int)N, (int)P, scale, (f16*)out, s);
-    else if (mode == KEEP_SIM_TOP2SCORE) {
-        float* partial = (float*)(h->arena + align_up((size_t)N * P * 4));
-        launch_top2_score(logits, (int)N, (int)P, partial, (float*)out, s);
+    char* b = h->cls_buf;
+    float* feats = feats_out ? feats_out : (float*)(b + o_feats);
+    float* sim = sim_out ? sim_out : (float*)(b + o_sim);
+    int* list = (int*)(b + o_list);
+    int rc = encode_image_run(h, pixels, pix_dtype, B, feats, s);
+    if (rc) return rc;
+    rc = similarity_run(h, feats, txt, B, P, D, scale, KEEP_SIM_ARGMAX, sim, labels_out, s);
+    if (rc) return rc;
+    if (margin == 0.f || P == 1 || h->precision == KEEP_PREC_STRICT) return check_launch(h, "classify");
+    launch_top2_margin_flags(sim, (int)B, (int)P, margin * scale, (int*)(b + o_flags), list, (int*)(b + o_count), s);
+    int count = 0;
+    HIPCHK(h, hipMemcpyAsync(&count, b + o_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));                                 // the one host round trip of the call: how many tiles to look at again
+    if (n_rechecked) *n_rechecked = count;
+    if (count == 0) return check_launch(h, "classify");
+    const int saved = h->precision;
+    h->precision = KEEP_PREC_STRICT;                                    // per call, no option epoch: graph keys carry the precision
+    for (int64_t c0 = 0; c0 < count && !rc; c0 += stage_tiles) {
+        const int n = (int)((count - c0) < stage_tiles ? (count - c0) : stage_tiles);
+        launch_gather_tiles(pixels, (int64_t)tile_bytes, list + c0, n, b + o_stage, s);
+        rc = encode_image_run(h, b + o_stage, pix_dtype, n, (float*)(b + o_f2), s);
+        if (!rc) launch_scatter_rows((const float*)(b + o_f2), list + c0, n, D, feats, s);
     }
-    return check_launch(h, "similarity");
+    h->precision = saved;
+    if (rc) return rc;
+    rc = similarity_run(h, feats, txt, B, P, D, scale, KEEP_SIM_ARGMAX, sim, labels_out, s);
+    if (rc) return rc;
+    return check_launch(h, "classify");
 }
 
 int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, int64_t N, int64_t K, int64_t C, int64_t D,

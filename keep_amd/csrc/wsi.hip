@@ -299,6 +299,59 @@ void sim_mid_kernel(const float* __restrict__ img, const float* __restrict__ txt
     }
 }
 
+
+// ---- keep_classify: which tiles need the accurate arithmetic, and moving them ---------------------------------------------
+// flags[r] = 1 where the two largest entries of sim row r are closer than `bound` (a label the default arithmetic cannot vouch for)
+__global__ __launch_bounds__(256)
+void top2_margin_flag_kernel(const float* __restrict__ sim, int N, int P, float bound, int* __restrict__ flags) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const float* x = sim + (int64_t)r * P;
+    float v1 = -INFINITY, v2 = -INFINITY;
+    for (int c = 0; c < P; ++c) {
+        const float v = x[c];
+        if (v > v1) { v2 = v1; v1 = v; } else if (v > v2) v2 = v;
+    }
+    // NaN-safe: a row with a non-finite entry is always re-examined
+    flags[r] = (P > 1 && !(v1 - v2 >= bound)) ? 1 : 0;
+}
+// ordered compaction of the flagged row indices by ONE workgroup (N is a slide's tile count: a few thousand to a few hundred thousand)
+__global__ __launch_bounds__(1024)
+void compact_flags_kernel(const int* __restrict__ flags, int N, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 1024) {
+        const int i = i0 + tid;
+        const int f = (i < N && flags[i] != 0) ? 1 : 0;
+        const unsigned long long b = __ballot(f);
+        const int pre = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int k = 0; k < w; ++k) off += wsum[k];
+        if (f) list[off + pre] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; base_s += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+__global__ __launch_bounds__(256)
+void gather_tiles_kernel(const uint4* __restrict__ src, int64_t tile_vec, const int* __restrict__ list, uint4* __restrict__ dst) {
+    const int t = blockIdx.y;
+    const uint4* s = src + (int64_t)list[t] * tile_vec;
+    uint4* d = dst + (int64_t)t * tile_vec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tile_vec; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ __launch_bounds__(256)
+void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ list, int D, float* __restrict__ dst) {
+    const int t = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) dst[(int64_t)list[t] * D + c] = src[(int64_t)t * D + c];
+}
+
 }  // namespace keepk
 using namespace keepk;
 
@@ -359,4 +412,15 @@ void launch_refine(const float* probs, const long long* coords, int n, int C, lo
     const int64_t total = (int64_t)n * C;
     hipLaunchKernelGGL(refine_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, probs, coords, n, C, patch, overlap,
                        keys, first, table_size - 1, out, is_first);
+}
+
+void launch_top2_margin_flags(const float* sim, int N, int P, float bound, int* flags, int* list, int* count, hipStream_t s) {
+    hipLaunchKernelGGL(top2_margin_flag_kernel, dim3((N + 255) / 256), dim3(256), 0, s, sim, N, P, bound, flags);
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, s, flags, N, list, count);
+}
+void launch_gather_tiles(const void* src, int64_t tile_bytes, const int* list, int n, void* dst, hipStream_t s) {
+    hipLaunchKernelGGL(gather_tiles_kernel, dim3(32, n), dim3(256), 0, s, (const uint4*)src, tile_bytes / 16, list, (uint4*)dst);
+}
+void launch_scatter_rows(const float* src, const int* list, int n, int D, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(256), 0, s, src, list, D, dst);
 }

@@ -236,6 +236,10 @@ class KEEPModel:
             _lib.check(self._handle, _lib.load().keep_set_option(self._handle, name.encode(), float(value)), name)
         return self
 
+    def get_option(self, name: str) -> float:
+        self._ready_device()
+        return float(_lib.load().keep_get_option(self._handle, name.encode()))
+
     def reserve(self, tiles: int = 0, prompts: int = 0, seq: int = 256):
         self._ready()
         _lib.check(self._handle, _lib.load().keep_reserve(self._handle, tiles, prompts, seq), "reserve")
@@ -458,6 +462,44 @@ class KEEPModel:
         if mode == "top2score":
             return float(out.item())
         return out
+
+    @torch.no_grad()
+    def classify(self, image_inputs: torch.Tensor, text_features: torch.Tensor, scale: float = 1.0, margin: Optional[float] = None,
+                 return_features: bool = False):
+        """Tiles -> (similarity [B,P] fp32, labels [B] int32[, features [B,768]]): ``encode_image`` + ``img @ txt.T`` + row argmax
+        (keep_inference.py:101-104) with labels that are the fp32 reference's.  Every tile is encoded in the model's precision; the
+        tiles whose two best prompts are closer than ``margin`` in cosine (default: the engine's ``label_margin``, 2.5e-4 = twice the
+        1e-4 tolerance + 25 %) are encoded a second time with split products (``strict``) and take their row from that.
+        ``self.last_rechecked`` holds how many tiles that was.  ``text_features``: ``encode_text`` output ([P,768], unit norm)."""
+        self._ready()
+        x = image_inputs
+        u8 = x.dtype == torch.uint8
+        if u8:
+            if x.dim() != 4 or tuple(x.shape[1:]) != (224, 224, 3):
+                raise ValueError(f"uint8 tiles must be [B,224,224,3] (HWC), got {tuple(x.shape)}")
+        else:
+            if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != 224 or x.shape[3] != 224:
+                raise ValueError(f"expected [B,3,224,224], got {tuple(x.shape)}")
+            if x.dtype not in _PIX:
+                x = x.to(torch.float32)
+        src_dev = x.device
+        txt = text_features.to(self._device, torch.float32).contiguous()
+        D = self.config.projection_dim
+        if txt.dim() != 2 or txt.shape[1] != D:
+            raise ValueError(f"text_features must be [P,{D}], got {tuple(txt.shape)}")
+        B, P = x.shape[0], txt.shape[0]
+        sim = torch.empty((B, P), dtype=torch.float32, device=self._device)
+        lab = torch.empty((B,), dtype=torch.int32, device=self._device)
+        feats = torch.empty((B, D), dtype=torch.float32, device=self._device) if return_features else None
+        n = C.c_int64(0)
+        if B:
+            xd = x.to(self._device, non_blocking=True).contiguous()
+            _lib.check(self._handle, _lib.load().keep_classify(self._handle, _ptr(xd), _lib.PIX_U8_HWC if u8 else _PIX[xd.dtype], B, _ptr(txt), P,
+                                                               float(scale), -1.0 if margin is None else float(margin), _ptr(feats), _ptr(sim),
+                                                               _ptr(lab), C.byref(n), _stream(self._device)), "classify")
+        self.last_rechecked = int(n.value)
+        out = (sim, lab) + ((feats,) if return_features else ())
+        return out if src_dev == self._device else tuple(t.to(src_dev) for t in out)
 
     def _ready_device(self):
         self.check_errors(wait=False)
