@@ -151,9 +151,14 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
 int keep_encode_text(keep_handle* h, const int64_t* input_ids, const int64_t* token_type_ids,
                      const int64_t* attention_mask, int64_t P, int64_t T, float* out, void* stream);
 
-/* 1 if any token / type id of a keep_encode_text call on `stream` SINCE THE LAST TIME THIS RETURNED 1 was out of range (the kernel
- * clamps it; the reference's nn.Embedding would raise IndexError).  The device-side flag is sticky -- encode calls only ever set it --
- * and is cleared here, once the host has seen it, so an error can not be lost between calls.  Synchronises `stream`. */
+/* The handle's sticky error bits, set by encode calls on `stream` SINCE THE LAST TIME THIS RETURNED NON-ZERO:
+ *   bit 0 (1): a token / type id of a keep_encode_text call was out of range (the kernel clamps it; the reference's nn.Embedding
+ *              would raise IndexError);
+ *   bit 1 (2): an output feature row of keep_encode_image / keep_encode_text was not finite: an activation left the fp16 range
+ *              (|x| > 65504 in a qkv / MLP-hidden store -- conversions do not saturate, so the overflow reaches the output as NaN
+ *              instead of as plausible garbage; the fp32 reference would not overflow).
+ * Encode calls only ever SET bits; they are cleared here, once the host has seen them, so an error can not be lost between calls.
+ * Synchronises `stream`. */
 int keep_token_error(keep_handle* h, void* stream);
 /* The same without a host synchronisation: enqueues a copy of the (sticky) flag into `host_flag` (pinned host memory owned by the
  * caller, which must stay alive until the stream has passed that point) behind the work already on `stream`.  Does not clear the flag:

@@ -14,15 +14,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // fp16 has 65504 as its largest finite value: saturate instead of producing inf
 // (ViT residual streams can carry outlier channels; the stream itself stays fp32).
-__device__ __forceinline__ f16 to_f16_sat(float x) {
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
-    return (f16)x;
-}
-
 // hi/lo split used by the "strict" (3-pass) precision mode: x ~= hi + lo with
 // hi = fp16(x), lo = fp16(x - hi).  |x - hi - lo| <= 2^-22 |x| (2^-25 abs floor).
+// No saturation: a value beyond the fp16 range (65504) becomes inf on purpose -- it turns into NaN at the next LayerNorm / softmax and the
+// final normalisation kernel raises the handle's "non-finite features" flag (the reference computes in fp32 and would not overflow;
+// clamping would return plausible garbage instead).
 __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
-    hi = to_f16_sat(x);
+    hi = (f16)x;
     lo = (f16)(x - (float)hi);
 }
 
@@ -186,7 +184,7 @@ void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hip
 void launch_quant_blockify(const float* src, f16* hi, f16* lo, unsigned char* q, unsigned char* sc, int M, int K, hipStream_t s);
 // blk-layout fp16 hi (+lo) -> row-major fp32 [M][K]
 void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s);
-void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s);
+void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s, int* err_flag = nullptr);   // err_flag |= 2 if a row is not finite
 void launch_row_argmax(const float* x, int rows, int cols, int32_t* out, hipStream_t s);
 void launch_row_softmax(const float* x, int rows, int cols, float scale, float* out, hipStream_t s);
 void launch_row_softmax_f16(const float* x, int rows, int cols, float scale, f16* out, hipStream_t s);

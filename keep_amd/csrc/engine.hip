@@ -114,7 +114,7 @@ struct keep_handle {
     // workspace arena
     char* arena = nullptr;
     size_t arena_bytes = 0;
-    int* err_flag = nullptr;     // device int: out-of-range token ids
+    int* err_flag = nullptr;     // device int, sticky: bit 0 out-of-range token ids, bit 1 non-finite output features (fp16 range exceeded)
 
     // profiling
     int prof_mode = 0;           // 0 off, 1 single tag, 2 all
@@ -512,7 +512,7 @@ int vit_end(keep_handle* h, VitLane& L) {
         g.a = ws.h1; g.lda = h->proj_dim; g.b = w2->f32; g.ldb = h->proj_dim; g.out = out; g.ldo = h->proj_dim;
         g.bias = find(h, "visual_head.2.bias")->f32; g.K = h->proj_dim; g.act = ACT_NONE;
         if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "visual_head.2 shape");
-        launch_l2norm_rows(out, Bc, h->proj_dim, 1e-12f, s);
+        launch_l2norm_rows(out, Bc, h->proj_dim, 1e-12f, s, h->err_flag);
     }
     return check_launch(h, "encode_image");
 }
@@ -596,7 +596,7 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
         g.b = find(h, "text.pooler.dense.weight")->f32; g.ldb = H; g.out = out; g.ldo = H;
         g.bias = find(h, "text.pooler.dense.bias")->f32; g.M = Pc; g.N = H; g.K = H; g.scale = 1.f; g.act = ACT_TANH;
         if (launch_sgemm_f32(g, s)) return h->fail(KEEP_EUNSUPPORTED, "pooler shape");
-        launch_l2norm_rows(out, Pc, H, 1e-12f, s);
+        launch_l2norm_rows(out, Pc, H, 1e-12f, s, h->err_flag);
     }
     return check_launch(h, "encode_text");
 }
@@ -1202,7 +1202,7 @@ int keep_token_error(keep_handle* h, void* stream) {
     HIPCHK(h, hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     if (flag) HIPCHK(h, hipMemsetAsync(h->err_flag, 0, sizeof(int), (hipStream_t)stream));     // seen by the host: re-arm
-    return flag ? 1 : 0;
+    return flag & 3;
 }
 
 int keep_token_error_async(keep_handle* h, int32_t* host_flag, void* stream) {

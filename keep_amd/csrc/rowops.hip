@@ -281,7 +281,7 @@ __global__ void unblockify_f32_kernel(const f16* __restrict__ hi, const f16* __r
 
 // ------------------------------------------------------------------ row L2 normalise (in place)
 __global__ __launch_bounds__(256)
-void l2norm_rows_kernel(float* __restrict__ x, int rows, int D, float eps) {
+void l2norm_rows_kernel(float* __restrict__ x, int rows, int D, float eps, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -289,6 +289,8 @@ void l2norm_rows_kernel(float* __restrict__ x, int rows, int D, float eps) {
     float sq = 0.f;
     for (int i = lane; i < D; i += 64) sq += r[i] * r[i];
     const float nrm = sqrtf(wave_sum(sq));
+    // a NaN / inf here means an activation left the fp16 range somewhere upstream (conversions do not saturate: common.h split_f16)
+    if (err_flag && lane == 0 && !(nrm < INFINITY)) atomicOr(err_flag, 2);
     const float inv = 1.0f / fmaxf(nrm, eps);
     for (int i = lane; i < D; i += 64) r[i] *= inv;
 }
@@ -553,8 +555,8 @@ void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int 
     hipLaunchKernelGGL(unblockify_f32_kernel, dim3(blocks), dim3(256), 0, s, hi, lo, out, M, K);
 }
 
-void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, D, eps);
+void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s, int* err_flag) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, D, eps, err_flag);
 }
 void launch_row_argmax(const float* x, int rows, int cols, int32_t* out, hipStream_t s) {
     hipLaunchKernelGGL(row_argmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, cols, out);

@@ -27,6 +27,10 @@ from .config import KEEPShape
 _PIX = {torch.float32: _lib.PIX_F32, torch.float16: _lib.PIX_F16, torch.bfloat16: _lib.PIX_BF16}
 _PRECISIONS = {"fp16": _lib.PREC_FP16, "strict": _lib.PREC_STRICT, "comp": _lib.PREC_COMP}
 DEFAULT_PRECISION = "comp"     # the mode that meets the reference tolerance (cosines within 1e-4) at the lowest cost
+# 'comp' settings in order of cost: (comp_full_blocks, comp_mlp_blocks) = blocks whose attention side runs split products / whose MLP GEMMs
+# carry the MX-fp4 correction terms.  calibrate() walks up this ladder until the probe's worst cosine error is inside its target.
+COMP_LADDER = ((1, 8), (1, 10), (1, 12), (2, 12), (2, 16), (2, 24), (4, 24), (8, 24), (24, 24))
+CALIBRATION_TARGET = 0.7e-4    # of the 1e-4 tolerance: head-room for the larger population of a real slide and for other tiles
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -71,6 +75,11 @@ class KEEPModel:
         self.check_token_ids = "lazy"
         self._pending_token_checks = []   # [(pinned int32 flag, event)] in issue order; the device flag is sticky, so none can be lost
         self._flag_pool = []              # pinned buffers are recycled only after their copy has landed
+        # load_state_dict on a GPU ends with calibrate(): the cheapest 'comp' setting whose worst cosine error on a seeded probe batch
+        # (against the engine's own split-product arithmetic) stays inside CALIBRATION_TARGET.  KEEP_CALIBRATE=0 / auto_calibrate=False: keep the
+        # built-in default (1, 8), which was chosen on ONE synthetic weight family.
+        self.auto_calibrate = os.environ.get("KEEP_CALIBRATE", "1") != "0"
+        self.calibration: Optional[dict] = None
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
 
@@ -195,6 +204,9 @@ class KEEPModel:
                                    + ' (construct with towers=("image",) / ("text",) for a single-tower engine)')
         self._loaded = True
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1      # invalidates per-model prompt caches (keep_amd.wsi)
+        self.calibration = None
+        if self.auto_calibrate and self._options["precision"] == _lib.PREC_COMP and lib.keep_vit_depth(h) > 0:
+            self.calibrate()
 
     @classmethod
     def from_pretrained(cls, path: str, precision: str = DEFAULT_PRECISION, **_ignored) -> "KEEPModel":
@@ -236,6 +248,67 @@ class KEEPModel:
             _lib.check(self._handle, _lib.load().keep_set_option(self._handle, name.encode(), float(value)), name)
         return self
 
+    @torch.no_grad()
+    def calibrate(self, n_tiles: int = 256, target: float = CALIBRATION_TARGET, tiles: Optional[torch.Tensor] = None,
+                  text_features: Optional[torch.Tensor] = None, seed: int = 20250929) -> Optional[dict]:
+        """Pick the 'comp' setting for THESE weights instead of trusting the one tuned on the synthetic default family.
+
+        A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded
+        once with split products (the engine's fp32-class arithmetic, ~5e-7 from the fp32 reference) and then with each rung of
+        ``COMP_LADDER`` from the cheapest up; the first rung whose worst |cos - cos_split| over probe tiles x prompts is <= ``target``
+        is kept (``comp_full_blocks`` / ``comp_mlp_blocks`` options).  The prompts are ``text_features`` ([P,768] unit rows; default:
+        64 seeded prompts through the loaded text tower, or 64 seeded random unit vectors for an image-only engine).  If even the last
+        rung misses, the engine switches to 'strict'.  Non-finite probe features (an activation beyond the fp16 range) raise
+        FloatingPointError.  Returns and stores ``self.calibration``."""
+        lib, h = _lib.load(), self._handle
+        if not self._loaded and self._host_sd is not None:
+            self.to("cuda")
+            if self.calibration is not None:
+                return self.calibration
+        if not h.value or lib.keep_vit_depth(h) == 0 or self._options["precision"] != _lib.PREC_COMP:
+            return None
+        dev, depth = self._device, int(lib.keep_vit_depth(h))
+        if tiles is None:
+            g = torch.Generator(device=dev).manual_seed(seed)
+            tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+        tiles = tiles.to(dev)
+        if text_features is None:
+            if lib.keep_bert_layers(h) > 0:
+                from .synth import synth_prompts
+                toks = synth_prompts(64, 64, seed=seed % 100003, vocab=self.config.text.vocab_size)
+                text_features = self.encode_text({k: v.to(dev) for k, v in toks.items()})
+            else:
+                g = torch.Generator().manual_seed(seed + 1)
+                text_features = torch.nn.functional.normalize(torch.randn(64, self.config.projection_dim, generator=g), dim=-1)
+        bank = text_features.to(dev, torch.float32).t().contiguous()
+        was, self.auto_calibrate = self.auto_calibrate, False
+        try:
+            self.set_precision("strict")
+            ref = self.encode_image(tiles) @ bank
+            self.set_precision("comp", self._options.get("strict_blocks", 0))
+            if not bool(torch.isfinite(ref).all()):
+                self._raise_flags(2)
+            tried, chosen = [], None
+            rungs = list(dict.fromkeys((min(a, depth), min(b, depth)) for a, b in COMP_LADDER))
+            for full, mlp in rungs:
+                self.set_option("comp_full_blocks", full)
+                self.set_option("comp_mlp_blocks", mlp)
+                d = (self.encode_image(tiles) @ bank - ref).abs()
+                err, rms = float(d.max()), float(d.pow(2).mean().sqrt())
+                tried.append({"comp_full_blocks": full, "comp_mlp_blocks": mlp, "max_abs_dcos": float(f"{err:.3e}"), "rms_dcos": float(f"{rms:.3e}")})
+                if err <= target:             # (NaN compares False: falls through to the next rung)
+                    chosen = (full, mlp)
+                    break
+            if chosen is None:
+                self.set_precision("strict")
+            self.check_errors(wait=True)
+        finally:
+            self.auto_calibrate = was
+        self.calibration = {"precision": "comp" if chosen else "strict", "comp_full_blocks": chosen[0] if chosen else None,
+                            "comp_mlp_blocks": chosen[1] if chosen else None, "target_max_abs_dcos": target,
+                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[1]} prompts vs the split-product arithmetic", "tried": tried}
+        return self.calibration
+
     def get_option(self, name: str) -> float:
         self._ready_device()
         return float(_lib.load().keep_get_option(self._handle, name.encode()))
@@ -274,7 +347,12 @@ class KEEPModel:
         lib = _lib.load()
         _lib.check(self._handle, lib.keep_encode_image(self._handle, _ptr(xd), _PIX[xd.dtype], xd.shape[0], _ptr(out),
                                                        _stream(self._device)), "encode_image")
-        return out if src_dev == self._device else out.to(src_dev)
+        self._queue_flag_check(_stream(self._device))
+        if src_dev == self._device:
+            return out
+        res = out.to(src_dev)
+        self.check_errors(wait=True)
+        return res
 
     @torch.no_grad()
     def encode_image_uint8(self, tiles_u8: torch.Tensor) -> torch.Tensor:
@@ -292,6 +370,7 @@ class KEEPModel:
         out = torch.empty((xd.shape[0], self.config.projection_dim), dtype=torch.float32, device=self._device)
         _lib.check(self._handle, _lib.load().keep_encode_image(self._handle, _ptr(xd), _lib.PIX_U8_HWC, xd.shape[0], _ptr(out),
                                                                _stream(self._device)), "encode_image_uint8")
+        self._queue_flag_check(_stream(self._device))
         return out if src_dev == self._device else out.to(src_dev)
 
     @torch.no_grad()
@@ -377,6 +456,18 @@ class KEEPModel:
         st = _stream(self._device)
         _lib.check(self._handle, lib.keep_encode_text(self._handle, _ptr(ids_d), _ptr(typ_d), _ptr(msk_d), P, T,
                                                       _ptr(out), st), "encode_text")
+        self._queue_flag_check(st)
+        if src_dev == self._device:
+            return out
+        res = out.to(src_dev)                  # host inputs: the copy back synchronises anyway, so the check is free and immediate
+        self.check_errors(wait=True)
+        return res
+
+    def _queue_flag_check(self, st):
+        """After an encode call: look at the handle's sticky error bits (out-of-range token ids, non-finite features) -- immediately
+        (``check_token_ids=True``), not at all (False), or lazily: an asynchronous copy of the bits + an event, examined by the next
+        engine call / ``check_errors()`` (no host synchronisation per call)."""
+        lib = _lib.load()
         if self.check_token_ids == "lazy":
             if len(self._pending_token_checks) >= 64:                  # bound the queue: wait for the oldest copies
                 self.check_errors(wait=True)
@@ -385,37 +476,41 @@ class KEEPModel:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self._device))
             self._pending_token_checks.append((flag, ev))
-        elif self.check_token_ids and lib.keep_token_error(self._handle, st) == 1:
-            raise IndexError("index out of range in self (input_ids / token_type_ids outside the embedding tables)")
-        if src_dev == self._device:
-            return out
-        res = out.to(src_dev)                  # host inputs: the copy back synchronises anyway, so the check is free and immediate
-        self.check_errors(wait=True)
-        return res
+        elif self.check_token_ids:
+            self._raise_flags(lib.keep_token_error(self._handle, st))
+
+    @staticmethod
+    def _raise_flags(bits: int, earlier: bool = False):
+        when = " of an earlier call" if earlier else ""
+        if bits & 1:
+            raise IndexError(f"index out of range in self (input_ids / token_type_ids{when} were outside the embedding tables)")
+        if bits & 2:
+            raise FloatingPointError(f"non-finite output features{when}: an activation exceeded the fp16 range (65504) of the engine's qkv / "
+                                     "MLP-hidden stores; these weights need the fp32 reference path")
 
     def check_errors(self, wait: bool = True):
-        """Raise the IndexError of an earlier ``encode_text`` call whose token ids were out of range (lazy checking).  Called by
-        every engine entry point with ``wait=False`` (only looks at copies that have already landed).  The device-side flag is
-        sticky and every call's copy is queued, so an error is reported by the first check after it -- never dropped."""
+        """Raise the error of an earlier encode call (lazy checking): IndexError for out-of-range token ids, FloatingPointError for
+        non-finite features.  Called by every engine entry point with ``wait=False`` (only looks at copies that have already landed).
+        The device-side bits are sticky and every call's copy is queued, so an error is reported by the first check after it --
+        never dropped."""
         pend = self._pending_token_checks
         if not pend:
             return
         if wait:
             pend[-1][1].synchronize()
-        bad = False
+        bits = 0
         while pend and pend[0][1].query():
             flag, _ = pend.pop(0)
-            bad = bad or int(flag.item()) != 0
+            bits |= int(flag.item())
             self._flag_pool.append(flag)
-        if bad:
-            # acknowledge (clears the sticky flag); copies still in flight were taken before the clear and would repeat the report
-            _lib.load().keep_token_error(self._handle, _stream(self._device))
+        if bits:
+            # acknowledge (clears the sticky bits); copies still in flight were taken before the clear and would repeat the report
+            bits |= _lib.load().keep_token_error(self._handle, _stream(self._device))
             for flag, ev in pend:
                 ev.synchronize()
                 self._flag_pool.append(flag)
             pend.clear()
-            raise IndexError("index out of range in self (input_ids / token_type_ids of an earlier encode_text call were outside "
-                             "the embedding tables)")
+            self._raise_flags(bits, earlier=True)
 
     def forward(self, image_inputs, text_inputs):
         """keep_inference.py:65-73."""
@@ -497,6 +592,7 @@ class KEEPModel:
             _lib.check(self._handle, _lib.load().keep_classify(self._handle, _ptr(xd), _lib.PIX_U8_HWC if u8 else _PIX[xd.dtype], B, _ptr(txt), P,
                                                                float(scale), -1.0 if margin is None else float(margin), _ptr(feats), _ptr(sim),
                                                                _ptr(lab), C.byref(n), _stream(self._device)), "classify")
+            self._queue_flag_check(_stream(self._device))
         self.last_rechecked = int(n.value)
         out = (sim, lab) + ((feats,) if return_features else ())
         return out if src_dev == self._device else tuple(t.to(src_dev) for t in out)

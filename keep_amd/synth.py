@@ -17,8 +17,21 @@ import torch
 from .config import KEEPShape
 
 
+FAMILIES = ("default", "heavy_tail", "small_ls")
+
+
 def synth_state_dict(shape: KEEPShape = KEEPShape(), seed: int = 0,
-                     vision: bool = True, text: bool = True) -> Dict[str, torch.Tensor]:
+                     vision: bool = True, text: bool = True, family: str = "default") -> Dict[str, torch.Tensor]:
+    """``family`` selects the weight distribution of the image tower (the text tower is the same in all three):
+      default     W ~ N(0, 0.02-0.03), LN gamma 1 +- 0.1, LayerScale ~ U(0.05, 0.5)                      
+      heavy_tail  trained-ViT pathologies: a few "massive" residual channels (cls / pos_embed / block biases 50-100 x the rest),
+                  outlier LayerNorm gains (x4-8 on a few channels, x0.15 on the massive ones), heavy-tailed linear weights
+                  (scale mixture: 4.5 % of the entries x3, 0.5 % x8, renormalised to the same std)
+      small_ls    LayerScale ~ U(0.003, 0.03): blocks that barely move the residual stream (the regime just after timm's 1e-5 init)
+    The default family draws exactly what it always drew (the committed fixtures depend on it); the others transform it with a second
+    generator."""
+    if family not in FAMILIES:
+        raise ValueError(f"family {family!r}: one of {FAMILIES}")
     g = torch.Generator(device="cpu").manual_seed(seed)
 
     def normal(*size, std=0.02):
@@ -75,7 +88,42 @@ def synth_state_dict(shape: KEEPShape = KEEPShape(), seed: int = 0,
             linear(p + "output.dense", h, t.intermediate_size, sd, std=0.02)
             ln(p + "output.LayerNorm", h, sd)
         linear("text.pooler.dense", h, h, sd)
+    if vision and family != "default":
+        _apply_family(sd, shape, family, seed)
     return sd
+
+
+def _apply_family(sd: Dict[str, torch.Tensor], shape: KEEPShape, family: str, seed: int) -> None:
+    g = torch.Generator(device="cpu").manual_seed(seed * 7919 + 17)
+    v = shape.vision
+    d = v.embed_dim
+    if family == "small_ls":
+        for i in range(v.depth):
+            for k in ("ls1", "ls2"):
+                sd[f"visual.blocks.{i}.{k}.gamma"] = torch.rand(d, generator=g) * 0.027 + 0.003
+        return
+    massive = torch.randperm(d, generator=g)[:6]
+    sign = torch.where(torch.rand(6, generator=g) < 0.5, -1.0, 1.0)
+    sd["visual.cls_token"][0, 0, massive] = sign * (1.0 + torch.rand(6, generator=g))               # 50-100 x the 0.02 of the others
+    sd["visual.pos_embed"][0, :, massive] += (sign * (1.0 + torch.rand(6, generator=g)))[None, :]
+    for i in range(v.depth):
+        p = f"visual.blocks.{i}."
+        for name in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            w = sd[p + name + ".weight"]
+            u = torch.rand(w.shape, generator=g)
+            mix = torch.where(u < 0.005, 8.0, torch.where(u < 0.05, 3.0, 1.0))
+            std0 = float(w.std())
+            w.mul_(mix)
+            w.mul_(std0 / float(w.std()))
+        for name in ("attn.proj", "mlp.fc2"):                                                      # biases that keep feeding the massive channels
+            sd[p + name + ".bias"][massive] = sign * (1.0 + 2.0 * torch.rand(6, generator=g))    # x LayerScale x 48 sub-blocks: those channels end 50-100 x the median |x|
+        for name in ("norm1", "norm2"):
+            gam = sd[p + name + ".weight"]
+            out = torch.randperm(d, generator=g)[:8]
+            gam[out] *= 4.0 + 4.0 * torch.rand(8, generator=g)
+            gam[massive] = 0.15
+    gam = sd["visual.norm.weight"]
+    gam[torch.randperm(d, generator=g)[:8]] *= 4.0 + 4.0 * torch.rand(8, generator=g)
 
 
 def synth_tiles(batch: int, seed: int = 0, dtype=torch.float32) -> torch.Tensor:

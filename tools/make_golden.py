@@ -447,6 +447,29 @@ def golden_c3(n_tiles: int = 4096, chunk: int = 256, n_prompts: int = 64):
     print(f"[c3] {n_tiles} x {n_prompts}: min top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.3e}")
 
 
+def golden_families(n_tiles: int = 96, n_prompts: int = 64, seed: int = 3):
+    """The two extra weight families of keep_amd.synth (heavy-tailed activations / outlier LayerNorm gains; tiny LayerScale) at full
+    depth through both oracle towers -> tests/golden/family_<name>.npz: the [n_tiles, n_prompts] cosine matrix, argmax, top-2 margins.
+    The oracle is pinned by the vit / bert sections; weights and tiles are regenerated from seeds on the GPU box."""
+    toks = synth_prompts(n_prompts, 256, seed=seed + 40)
+    for family in ("heavy_tail", "small_ls"):
+        sd = synth_state_dict(KEEPShape(), seed=seed, family=family)
+        x = synth_tiles(n_tiles, seed=700 + seed)
+        with torch.no_grad():
+            txt = O.encode_text(sd, toks)
+            img = torch.cat([O.encode_image(sd, x[i:i + 32]) for i in range(0, n_tiles, 32)])
+            tok = O.vit_tokens(sd, x[:4], 24)
+        assert bool(torch.isfinite(img).all())
+        sims = img @ txt.t()
+        top2 = sims.topk(2, dim=1).values
+        print(f"[family {family}] |token| max {float(tok.abs().max()):.1f} median {float(tok.abs().median()):.3f}; tile-tile cosine "
+              f"{float((img @ img.t())[0, 1]):.4f}; min top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.2e}")
+        np.savez_compressed(os.path.join(GOLD, f"family_{family}.npz"), family=family, weight_seed=seed, tile_seed=700 + seed, n_tiles=n_tiles,
+                            tiles_checksum=checksum(x), qkv0_checksum=checksum(sd["visual.blocks.0.attn.qkv.weight"]),
+                            input_ids=toks["input_ids"].numpy().astype(np.int32), attention_mask=toks["attention_mask"].numpy().astype(np.int8),
+                            sims=sims.numpy(), argmax=sims.argmax(1).numpy().astype(np.int16), margin=(top2[:, 0] - top2[:, 1]).numpy())
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -459,6 +482,8 @@ def main():
         golden_wsi_callers()
     if "signatures" in which:
         golden_signatures()
+    if "families" in which:
+        golden_families()
     if "bert2" in which:
         golden_bert(2, 4, seed=11)
     if "bert12" in which:
