@@ -184,6 +184,8 @@ void launch_split_blockify(const float* src, f16* hi, f16* lo, int M, int K, hip
 void launch_quant_blockify(const float* src, f16* hi, f16* lo, unsigned char* q, unsigned char* sc, int M, int K, hipStream_t s);
 // blk-layout fp16 hi (+lo) -> row-major fp32 [M][K]
 void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int K, hipStream_t s);
+// stats2[0] = max |w| (read as float), stats2[1] = sum w^2 -- the load-time range check of the fp16 operand planes
+void launch_weight_stats(const float* w, int64_t n, float* stats2, hipStream_t s);
 void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s, int* err_flag = nullptr);   // err_flag |= 2 if a row is not finite
 void launch_row_argmax(const float* x, int rows, int cols, int32_t* out, hipStream_t s);
 void launch_row_softmax(const float* x, int rows, int cols, float scale, float* out, hipStream_t s);

@@ -8,6 +8,7 @@
 #include "quant4.h"
 #include "../../include/keep_hip.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -609,6 +610,19 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         // fp16 hi/lo planes in blk layout; rows (out features) must fill whole 256-row tiles
         const int64_t n = t.shape[0], k = t.numel / t.shape[0];
         if (n % 256 || k % 32) return h->fail(KEEP_EUNSUPPORTED, "%s: [%lld,%lld] is not tileable (rows %% 256, cols %% 32)", key.c_str(), (long long)n, (long long)k);
+        // The GEMM operand planes are fp16: 11 significant bits between 6.1e-5 and 65504, fewer below (subnormals), none above.  A weight whose
+        // entries sit outside that window would be resolved worse than the error budget assumes -- and the split-product mode, which calibrate()
+        // measures against, would lose the same bits, so nothing downstream could notice.  Refuse it here instead.
+        {
+            float host[2] = {0.f, 0.f};
+            HIPCHK(h, hipMemsetAsync(h->err_flag + 2, 0, 2 * sizeof(float), nullptr));
+            launch_weight_stats(dev, t.numel, reinterpret_cast<float*>(h->err_flag + 2), nullptr);
+            HIPCHK(h, hipMemcpy(host, h->err_flag + 2, sizeof host, hipMemcpyDeviceToHost));
+            const double rms = sqrt((double)host[1] / (double)t.numel);
+            if (!(host[0] <= 6.0e4f)) return h->fail(KEEP_EUNSUPPORTED, "%s: max |w| = %g does not fit the fp16 operand planes (65504) or is not finite", key.c_str(), (double)host[0]);
+            if (rms > 0.0 && rms < 2.5e-4) return h->fail(KEEP_EUNSUPPORTED, "%s: rms %g is below what the fp16 operand planes resolve (entries fall into fp16 subnormals); "
+                                                          "rescale the checkpoint or use the fp32 reference path", key.c_str(), rms);
+        }
         HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
         HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
         // the MLP weights of the image tower also get the MX-fp4 side planes of the compensated product (quant4.h)
@@ -953,8 +967,8 @@ int keep_create(int device_id, keep_handle** out) {
     if (!guard.ok) return KEEP_EHIP;
     keep_handle* h = new keep_handle();
     h->device = device_id;
-    if (hipMalloc(&h->err_flag, sizeof(int)) != hipSuccess) { delete h; return KEEP_ENOMEM; }
-    hipMemset(h->err_flag, 0, sizeof(int));
+    if (hipMalloc(&h->err_flag, 4 * sizeof(int)) != hipSuccess) { delete h; return KEEP_ENOMEM; }     // [0] sticky error bits, [2..3] load-time weight statistics
+    hipMemset(h->err_flag, 0, 4 * sizeof(int));
     *out = h;
     return KEEP_OK;
 }

@@ -279,6 +279,19 @@ __global__ void unblockify_f32_kernel(const f16* __restrict__ hi, const f16* __r
     }
 }
 
+// ------------------------------------------------------------------ load-time range check of a GEMM weight: stats[0] = max |w| (as uint bits), stats[1] = sum w^2
+__global__ __launch_bounds__(256)
+void weight_stats_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ stats_max, float* __restrict__ stats_sq) {
+    float mx = 0.f, sq = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        mx = fmaxf(mx, fabsf(v)); sq += v * v;
+        if (!(fabsf(v) <= 3.0e38f)) mx = INFINITY;          // NaN / inf in a checkpoint
+    }
+    mx = wave_max(mx); sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) { atomicMax(stats_max, __float_as_uint(mx)); atomicAdd(stats_sq, sq); }
+}
+
 // ------------------------------------------------------------------ row L2 normalise (in place)
 __global__ __launch_bounds__(256)
 void l2norm_rows_kernel(float* __restrict__ x, int rows, int D, float eps, int* __restrict__ err_flag) {
@@ -555,6 +568,11 @@ void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int 
     hipLaunchKernelGGL(unblockify_f32_kernel, dim3(blocks), dim3(256), 0, s, hi, lo, out, M, K);
 }
 
+void launch_weight_stats(const float* w, int64_t n, float* stats2, hipStream_t s) {
+    (void)hipMemsetAsync(stats2, 0, 2 * sizeof(float), s);
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(weight_stats_kernel, dim3(blocks), dim3(256), 0, s, w, n, (unsigned*)stats2, stats2 + 1);
+}
 void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s, int* err_flag) {
     hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, D, eps, err_flag);
 }
