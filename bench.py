@@ -352,9 +352,14 @@ def main():
                                    f"({args.pixel_dtype} pixels; GEMM operands fp16 with fp32 accumulation, + MX-fp4 correction passes in 'comp'), 1xMI355X per rank",
                        "tiles_per_gpu_per_step": B, "precision": args.precision,
                        "exchange": "RCCL all_gather of [256,768] fp32 embeddings per step" if use_dist else "none",
+                       "comp_settings": {"comp_full_blocks": int(model.get_option("comp_full_blocks")), "comp_mlp_blocks": int(model.get_option("comp_mlp_blocks")),
+                                         "label_margin": model.get_option("label_margin"),
+                                         "chosen_by": "KEEPModel.calibrate() at load_state_dict" if model.calibration else "built-in default"},
                        "mfma_frac_end_to_end": round(frac_e2e, 4)},
             "roofline": roofline,
         }
+        if model.calibration is not None:
+            line["calibration"] = model.calibration
         if sustained is not None:
             line["sustained"] = sustained
         if parity is not None:

@@ -29,7 +29,7 @@ _PRECISIONS = {"fp16": _lib.PREC_FP16, "strict": _lib.PREC_STRICT, "comp": _lib.
 DEFAULT_PRECISION = "comp"     # the mode that meets the reference tolerance (cosines within 1e-4) at the lowest cost
 # 'comp' settings in order of cost: (comp_full_blocks, comp_mlp_blocks) = blocks whose attention side runs split products / whose MLP GEMMs
 # carry the MX-fp4 correction terms.  calibrate() walks up this ladder until the probe's worst cosine error is inside its target.
-COMP_LADDER = ((1, 8), (1, 10), (1, 12), (2, 12), (2, 16), (2, 24), (4, 24), (8, 24), (24, 24))
+COMP_LADDER = ((0, 0), (0, 4), (1, 4), (1, 6), (1, 8), (1, 10), (1, 12), (2, 12), (2, 16), (2, 24), (4, 24), (8, 24), (24, 24))
 CALIBRATION_TARGET = 0.7e-4    # of the 1e-4 tolerance: head-room for the larger population of a real slide and for other tiles
 
 
