@@ -89,6 +89,8 @@ struct keep_handle {
     int comp_mlp_blocks = 8;     // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
     int fused_screening = 1;     // keep_prompt_scores: 1 fused compensated GEMM (default) | 2 fused 3-pass split GEMM | 0 logits through HBM (any C)
     int comp_min_tiles = 32;     // lanes with fewer tiles take the split product where a compensated one is asked for (small-M kernels)
+    int comp_qkv = 1;            // KEEP_PREC_COMP, blocks < comp_full_blocks: the qkv GEMM as a compensated product (x1.5) instead of a split one (x3);
+                                 // q / k / v are still stored as hi + lo planes and the attention itself stays a split product
     // keep_classify: tiles whose top-2 cosine margin is below this are re-encoded in KEEP_PREC_STRICT before their label is taken.
     // Default = 2 x the north-star tolerance (both cosines of a pair can move by 1e-4 in opposite directions) + 25 %.
     float label_margin = 2.5e-4f;
@@ -152,7 +154,7 @@ struct keep_handle {
     bool txt_must_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
     bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
     bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 128 == 0)
-    bool any_comp() const { return precision == KEEP_PREC_COMP && comp_mlp_blocks > 0 && vit_has_q; }
+    bool any_comp() const { return precision == KEEP_PREC_COMP && vit_has_q && (comp_mlp_blocks > 0 || (comp_full_blocks > 0 && comp_qkv)); }
 
     bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && tag == prof_tag); }
     void prof_add_flops(int tag, double f) { if (prof_on(tag)) prof_flops[tag] += f; }
@@ -400,10 +402,14 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
 #else
     const bool skip_ln = false;
 #endif
+    // qkv of a split-attention block in the compensated mode: fp16 pass + MX-fp4 correction terms instead of three fp16 passes (lanes
+    // large enough for the 256x256 kernel; LayerNorm-1 then writes the fp4 planes of its output instead of the lo plane)
+    const bool qkv_q = sp && h->precision == KEEP_PREC_COMP && i >= h->strict_blocks && h->comp_qkv && Bc >= h->comp_min_tiles && b.qkv->q && ws.xn_q && !L.xn_ready;
     LnParams ln{};
     ln.tune = &h->tune;
     ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
-    ln.out_hi = ws.xn_hi; ln.out_lo = sp ? ws.xn_lo : nullptr; ln.out_kt = D / 32;
+    ln.out_hi = ws.xn_hi; ln.out_lo = (sp && !qkv_q) ? ws.xn_lo : nullptr; ln.out_kt = D / 32;
+    ln.out_q = qkv_q ? ws.xn_q : nullptr; ln.out_sc = qkv_q ? ws.xn_sc : nullptr;
     if (!L.xn_ready && !skip_ln) {
         Scope sc(h, T_VIT_LN, s);
         ln.gamma = b.n1w; ln.beta = b.n1b;
@@ -412,8 +418,9 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     L.xn_ready = false;
     {
         Scope sc(h, T_VIT_QKV, s);
-        GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp, b.qkv_b);
+        GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, b.qkv_b);
         p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
+        if (qkv_q) { p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.qkv->q; p.w_sc = b.qkv->sc; }
         if (run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "qkv GEMM launch failed");
     }
     mark(1);
@@ -626,7 +633,7 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
         HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
         // the MLP weights of the image tower also get the MX-fp4 side planes of the compensated product (quant4.h)
-        if (key.find(".mlp.fc") != std::string::npos && starts_with(key, "visual.") && k % 128 == 0 && k >= 256) {
+        if ((key.find(".mlp.fc") != std::string::npos || key.find(".attn.qkv.") != std::string::npos) && starts_with(key, "visual.") && k % 128 == 0 && k >= 256) {
             HIPCHK(h, hipMalloc(&t.q, keepk::q4_data_bytes(n, k)));
             HIPCHK(h, hipMalloc(&t.sc, keepk::q4_scale_bytes(n, k)));
             launch_quant_blockify(dev, t.hi, t.lo, t.q, t.sc, (int)n, (int)k, nullptr);
@@ -1049,6 +1056,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
     else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
     else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
+    else if (n == "comp_qkv") { h->comp_qkv = v ? 1 : 0; }
     else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
     else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
@@ -1091,6 +1099,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "comp_full_blocks") return h->comp_full_blocks;
     if (n == "comp_mlp_blocks") return h->comp_mlp_blocks;
     if (n == "comp_min_tiles") return h->comp_min_tiles;
+    if (n == "comp_qkv") return h->comp_qkv;
     if (n == "max_tiles") return h->max_tiles;
     if (n == "max_prompts") return h->max_prompts;
     if (n == "gemm_impl") return t.gemm_impl;
