@@ -95,6 +95,8 @@ int keep_bert_layers(keep_handle* h);
  *   "comp_full_blocks" KEEP_PREC_COMP: ViT blocks whose qkv / attention / proj run as split products (default 1)
  *   "comp_mlp_blocks"  KEEP_PREC_COMP: ViT blocks whose fc1 / fc2 run as compensated products (default 8)
  *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
+ *   "comp_qkv"         KEEP_PREC_COMP: 1 = the qkv GEMM of the split-attention blocks as a compensated product instead of a split one
+ *                     (default 0: +0.9 % at equal settings, but calibrate() then needs more compensated MLP blocks -- a net loss)
  *   "label_margin"     keep_classify: cosine margin below which a tile's label is re-derived in KEEP_PREC_STRICT (default 2.5e-4)
  *   "fused_screening"  keep_prompt_scores with C in {2, 4}: 1 (default) one compensated GEMM with the top-2 score taken in the
  *                     accumulator registers (no logits in HBM) | 2 the same with three fp16 passes | 0 chunked fp32 GEMM + reduction

@@ -89,8 +89,10 @@ struct keep_handle {
     int comp_mlp_blocks = 8;     // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
     int fused_screening = 1;     // keep_prompt_scores: 1 fused compensated GEMM (default) | 2 fused 3-pass split GEMM | 0 logits through HBM (any C)
     int comp_min_tiles = 32;     // lanes with fewer tiles take the split product where a compensated one is asked for (small-M kernels)
-    int comp_qkv = 1;            // KEEP_PREC_COMP, blocks < comp_full_blocks: the qkv GEMM as a compensated product (x1.5) instead of a split one (x3);
-                                 // q / k / v are still stored as hi + lo planes and the attention itself stays a split product
+    int comp_qkv = 0;            // 1: KEEP_PREC_COMP, blocks < comp_full_blocks: the qkv GEMM as a compensated product (x1.5) instead of a split one (x3);
+                                 // q / k / v still stored as hi + lo planes, attention still a split product.  Measured (round 3): +0.9 % at equal settings,
+                                 // but block 0's qkv is where the error budget is tightest (the 3 % of the rounding variance the fp4 terms leave is
+                                 // amplified by all 24 blocks): calibrate() then needs 10 compensated MLP blocks instead of 6 -- a net loss.  Off.
     // keep_classify: tiles whose top-2 cosine margin is below this are re-encoded in KEEP_PREC_STRICT before their label is taken.
     // Default = 2 x the north-star tolerance (both cosines of a pair can move by 1e-4 in opposite directions) + 25 %.
     float label_margin = 2.5e-4f;

@@ -467,14 +467,17 @@ def test_compensated_mode_takes_the_fp4_path_on_bench_sized_lanes(small, text_ba
         ref = O.encode_image(small, x) @ text_bank.t()
     errs = {}
     for name, precision, opts in (("fp16", "fp16", {}), ("comp", "comp", {}), ("comp, attention side plain", "comp", {"comp_full_blocks": 0}),
-                                  ("comp, one lane", "comp", {"streams": 1})):
-        m = make_model(small, precision)
+                                  ("comp, one lane", "comp", {"streams": 1}), ("comp, qkv of block 0 compensated instead of split", "comp", {"comp_qkv": 1})):
+        m = KEEPModel(precision=precision, towers=towers_of(small))
+        m.auto_calibrate = False                  # the built-in setting (1 / 8): this test is about the fp4 path, not about what calibrate() picks
+        m.load_state_dict(small, strict=True)
+        m.to("cuda:0")
         for k, v in opts.items():
             m.set_option(k, v)
         d = (m.encode_image(x.cuda()).cpu() @ text_bank.t() - ref).abs()
         errs[name] = (d.max().item(), d.pow(2).mean().sqrt().item())
         print(f"[64 tiles d2 {name}] max|dcos|={errs[name][0]:.3e} rms={errs[name][1]:.3e}")
-    assert errs["comp"][0] < COS_TOL and errs["comp, one lane"][0] < COS_TOL
+    assert errs["comp"][0] < COS_TOL and errs["comp, one lane"][0] < COS_TOL and errs["comp, qkv of block 0 compensated instead of split"][0] < COS_TOL
     assert errs["comp"][1] < 0.5 * errs["fp16"][1]
     assert errs["comp, attention side plain"][1] < 0.8 * errs["fp16"][1]
 
