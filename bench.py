@@ -95,6 +95,15 @@ def cpu_baseline(sd, tiles: int = 8, iters: int = 40, min_seconds: float = 10.0)
                       f"of KEEPModel.encode_image, same synthetic weights; CPU: {cpu_model_name()}"}
 
 
+def lib_sha16() -> str:
+    import hashlib
+    from keep_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return "unknown"
+
+
 def time_gpu(fn, dev, reps: int):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -276,6 +285,17 @@ def main():
     model.profile_disable()
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
 
+    # effective shader clock under this load: a one-wave probe (shader cycles against the 100 MHz reference counter) on a side stream, right after
+    # the timed region (the queue is still full of encodes: the probe lands between them) and again during the sustained region
+    side = torch.cuda.Stream(device=dev)
+    clock_samples = []
+
+    def sample_clock():
+        clock_samples.append(model.clock_probe(spin_us=300, stream=side))
+
+    for _ in range(3):
+        step()
+        sample_clock()
     sustained = None
     if not args.no_sustained:
         n_sus = max(args.steps, int(args.sustain_seconds / (elapsed / args.steps)) + 1)
@@ -283,7 +303,15 @@ def main():
         sustained = {"value": round(world * B * n_sus / el, 2), "unit": "tiles/s", "steps": n_sus, "seconds": round(el, 2),
                      "ms_per_step": round(el / n_sus * 1e3, 3),
                      "note": "same step, same barriers, timed for >= 10 s: the part sits at its power cap under this load, so this is the rate to plan with"}
+        for _ in range(8):                                          # (the timed regions themselves stay untouched: samples are taken around them)
+            step()
+            sample_clock()
         log(f"sustained region done: {n_sus} steps in {el:.1f} s")
+    torch.cuda.synchronize(dev)
+    mhz = sorted(100.0 * float(t[0]) / max(float(t[1]), 1.0) for t in (c.cpu() for c in clock_samples))
+    clock = {"effective_shader_MHz_median": round(mhz[len(mhz) // 2], 0), "min": round(mhz[0], 0), "max": round(mhz[-1], 0), "samples": len(mhz),
+             "how": "keep_clock_probe: one wavefront counting shader cycles against the 100 MHz reference for 300 us on a side stream while encode steps run",
+             "peak_quoted_at_MHz": 2400} if mhz else None
 
     # untimed pass on ONE internal stream: clean per-kernel times (lanes do not overlap) for the breakdown and for the
     # dominant kernel in isolation
@@ -320,28 +348,41 @@ def main():
         tiles_per_s = world * B * args.steps / elapsed
         avg_ms = dom_ms / max(dom_n, 1)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0     # algorithmic FLOPs (2*M*N*K per launch) / summed launch time
-        traffic = None
-        for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):         # rocprofv3 --pmc passes (see profiles/README.md)
-            tpath = os.path.join(ROOT, "profiles", name)
+        # HBM traffic of the dominant kernel: PMC counters need rocprofv3 around the process (separate FETCH_SIZE / WRITE_SIZE passes, guide's gfx950
+        # correction), so it is read from the committed summary of `tools/refresh_profiles.sh` and labelled with the library build it was taken on
+        traffic, traffic_src = None, None
+        for rnd in ("r03", "r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(DOMINANT_TAG, {}).get("bytes_per_launch")
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(DOMINANT_TAG, {}).get("bytes_per_launch")
+                    sha_path = os.path.join(ROOT, "profiles", f"{rnd}_lib_sha16.txt")
+                    sha = open(sha_path).read().strip() if os.path.exists(sha_path) else "unrecorded"
+                    traffic_src = (f"profiles/{rnd}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of the plain persistent fc1 kernel, "
+                                   f"measured on library build {sha}; this run's library is {lib_sha16()}")
                     break
                 except (OSError, ValueError):
                     traffic = None
         frac_e2e = tiles_per_s / world * vit_flops_per_tile() / (PEAK_F16_TFLOPS * 1e12)
         roofline = {"bound": "mfma", "kernel": "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,{persistent plain | +mxfp4 phase}> (vit.fc1)",
                     "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "timing": "two_lane_in_region",
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
                     "flops_per_launch": round(dom_flops / max(dom_n, 1), 1),
                     "frac_end_to_end": round(frac_e2e, 4),
-                    "note": "achieved = algorithmic FLOPs of the fc1 launches / their summed HIP-event durations INSIDE the timed region, where two "
-                            "sub-batch lanes share the GPU (a launch runs beside the other lane's kernels, as rocprofv3 sees it); `isolated` is the "
-                            "same kernel on a single stream; frac_end_to_end = tiles/s x 123.11 GFLOP / peak over the whole encoder"}
+                    "note": "achieved / frac (timing = two_lane_in_region) = algorithmic FLOPs of the fc1 launches / their summed HIP-event durations INSIDE the "
+                            "timed region, where two sub-batch lanes share the GPU: a launch's duration includes the time it waits beside the other lane's "
+                            "kernels (as rocprofv3 sees it), so this UNDERSTATES the kernel; single_stream.* is the same kernel with nothing else on the GPU "
+                            "(profiles/r03_rocprofv3_kernel_stats_single_stream.csv is the rocprofv3 view of that); frac_end_to_end = tiles/s x 123.11 GFLOP / "
+                            "peak over the whole encoder (the driver-checkable figure)"}
         if iso is not None:
-            iso["frac"] = round(iso["achieved"] / PEAK_F16_TFLOPS, 4)
-            roofline["isolated"] = iso
+            roofline["single_stream"] = {"achieved_single_stream": iso["achieved"], "frac_single_stream": round(iso["achieved"] / PEAK_F16_TFLOPS, 4),
+                                         "avg_launch_ms": iso["avg_launch_ms"], "launches": iso["launches"]}
+        if clock is not None:
+            roofline["clock"] = clock
+            roofline["frac_of_peak_at_effective_clock"] = round(frac_e2e * 2400.0 / clock["effective_shader_MHz_median"], 4)
         line = {
             "metric": "224x224 tiles encoded/sec (whole node)", "value": round(tiles_per_s, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -254,6 +254,10 @@ int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const fl
 int keep_op_sgemm(keep_handle* h, const float* a, const float* b, const float* bias, int64_t M, int64_t N,
                   int64_t K, float scale, int act, float* out, void* stream);
 int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream);
+/* measurement aid: one wavefront spins for ~spin_us microseconds and writes {shader-clock cycles, 100 MHz reference ticks} to device_out2
+ * (two int64 on the device): effective shader clock = cycles / ticks * 100 MHz.  Launched on a side stream next to a running workload it
+ * reads the clock the part actually sustains under that load (bench.py records it; the MFMA peak is quoted at 2.4 GHz). */
+int keep_clock_probe(keep_handle* h, int spin_us, long long* device_out2, void* stream);
 /* diagnostics: with option "gemm_dbg"=1 every GEMM launch records, per workgroup, four shader-clock
  * stamps [start, first K tile landed, main loop end, end]; this copies them to host memory. */
 int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes);

@@ -828,6 +828,16 @@ struct Tmp {
     template <typename T> T* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr; ptrs.push_back(p); return (T*)p; }
 };
 
+// one wave: shader-clock cycles (s_memtime) against the constant 100 MHz counter (s_memrealtime) over ~`spin_us` microseconds
+__global__ void clock_probe_kernel(long long* out, int spin_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long r0 = (long long)__builtin_amdgcn_s_memrealtime(), c0 = (long long)__builtin_readcyclecounter();
+    long long r1 = r0;
+    while (r1 - r0 < spin_ticks) { __builtin_amdgcn_s_sleep(32); r1 = (long long)__builtin_amdgcn_s_memrealtime(); }
+    const long long c1 = (long long)__builtin_readcyclecounter();
+    out[0] = c1 - c0; out[1] = r1 - r0;
+}
+
 __global__ void f16_planes_to_f32_kernel(const f16* hi, const f16* lo, float* out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (float)hi[i] + (lo ? (float)lo[i] : 0.f);
@@ -1618,6 +1628,13 @@ int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes) {
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(host_dst, h->tune.dbg, bytes, hipMemcpyDeviceToHost));
     return KEEP_OK;
+}
+
+int keep_clock_probe(keep_handle* h, int spin_us, long long* device_out2, void* stream) {
+    if (!h || !device_out2 || spin_us < 1 || spin_us > 100000) return h ? h->fail(KEEP_EINVAL, "bad clock_probe arguments") : KEEP_EINVAL;
+    KEEP_ON_DEVICE(h);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, device_out2, spin_us * 100);
+    return check_launch(h, "clock_probe");
 }
 
 int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stream) {

@@ -17,9 +17,14 @@ def mean_per_kernel(path, counter):
 
 fetch = mean_per_kernel(sys.argv[1], "FETCH_SIZE")
 write = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
-TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, false, true>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false, false>",
-        "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, false, true>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, false, true>",
-        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false, false>", "vit.attn": "attention_kernel<13, false, 8>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
+# template arguments: <BN, WM, WN, NSTAGE, EPI, COMP, PERS>
+TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>",
+        "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, true>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>",
+        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "vit.attn": "attention_kernel<13, false, 8>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
+# algorithmic bytes per launch of one 128-tile lane (M = 25 216 rows): operands read once + outputs written once (+ fp32 residual read-modify-write)
+M = 128 * 197
+ALGO = {"vit.fc1": 2 * (M * 1024 + 4096 * 1024) + 2 * M * 4096, "vit.qkv": 2 * (M * 1024 + 3072 * 1024) + 2 * M * 3072,
+        "vit.attn": 2 * M * 3072 + 2 * M * 1024, "vit.ln": 4 * M * 1024 + 2 * M * 1024}
 out = {}
 for tag, pat in TAGS.items():
     f = [(v, n) for k, (v, n) in fetch.items() if pat in k]
@@ -27,5 +32,8 @@ for tag, pat in TAGS.items():
     if f and w:
         out[tag] = {"kernel": pat, "fetch_kib_raw": round(f[0][0], 1), "write_kib": round(w[0][0], 1), "dispatches": f[0][1],
                     "bytes_per_launch": round((2 * f[0][0] + w[0][0]) * 1024)}
+        if tag in ALGO:
+            out[tag]["algorithmic_bytes_per_launch"] = ALGO[tag]
+            out[tag]["traffic_over_algorithmic"] = round(out[tag]["bytes_per_launch"] / ALGO[tag], 2)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
