@@ -288,10 +288,14 @@ def main():
     # effective shader clock under this load: a one-wave probe (shader cycles against the 100 MHz reference counter) on a side stream, right after
     # the timed region (the queue is still full of encodes: the probe lands between them) and again during the sustained region
     side = torch.cuda.Stream(device=dev)
+    clock_buf = torch.zeros(16, 2, dtype=torch.int64, device=dev)     # allocated and settled before the probes' neighbours are queued
+    torch.cuda.synchronize(dev)
     clock_samples = []
 
     def sample_clock():
-        clock_samples.append(model.clock_probe(spin_us=300, stream=side))
+        if len(clock_samples) < clock_buf.shape[0]:
+            clock_samples.append(clock_buf[len(clock_samples)])
+            model.clock_probe(clock_samples[-1], spin_us=300, stream=side)
 
     for _ in range(3):
         step()
@@ -308,7 +312,7 @@ def main():
             sample_clock()
         log(f"sustained region done: {n_sus} steps in {el:.1f} s")
     torch.cuda.synchronize(dev)
-    mhz = sorted(100.0 * float(t[0]) / max(float(t[1]), 1.0) for t in (c.cpu() for c in clock_samples))
+    mhz = sorted(100.0 * float(t[0]) / float(t[1]) for t in clock_buf[:len(clock_samples)].cpu() if float(t[1]) > 0)
     clock = {"effective_shader_MHz_median": round(mhz[len(mhz) // 2], 0), "min": round(mhz[0], 0), "max": round(mhz[-1], 0), "samples": len(mhz),
              "how": "keep_clock_probe: one wavefront counting shader cycles against the 100 MHz reference for 300 us on a side stream while encode steps run",
              "peak_quoted_at_MHz": 2400} if mhz else None

@@ -606,14 +606,15 @@ class KEEPModel:
         if not self._handle.value:
             self._create(torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0))
 
-    def clock_probe(self, spin_us: int = 200, stream: Optional["torch.cuda.Stream"] = None) -> torch.Tensor:
-        """Enqueue a shader-clock sample on ``stream`` (default: current): returns a device int64[2] = {shader cycles, 100 MHz ticks};
-        MHz = 100 * cycles / ticks once the stream has passed it."""
+    def clock_probe(self, out: torch.Tensor, spin_us: int = 300, stream: Optional["torch.cuda.Stream"] = None) -> None:
+        """Enqueue a shader-clock sample on ``stream`` (default: current) into ``out`` (device int64[2], allocated -- and its allocation
+        synchronised -- BEFORE the work the probe runs beside was queued: a fresh tensor handed to a side stream can be a recycled block
+        that kernels still pending on the allocating stream write to).  out = {shader cycles, 100 MHz ticks}; MHz = 100 * cycles / ticks."""
         self._ready_device()
-        out = torch.empty(2, dtype=torch.int64, device=self._device)        # (not zeros: a fill on the current stream could land after the probe)
+        if out.dtype != torch.int64 or out.numel() < 2 or out.device != self._device or not out.is_contiguous():
+            raise ValueError("clock_probe needs a contiguous int64[2] on the engine's device")
         st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self._device)
         _lib.check(self._handle, _lib.load().keep_clock_probe(self._handle, int(spin_us), _ptr(out), st), "clock_probe")
-        return out
 
     # ------------------------------------------------------------------ profiling passthrough
     def profile_enable(self, tag: Optional[str] = None):
