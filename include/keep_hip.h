@@ -108,8 +108,9 @@ int keep_bert_layers(keep_handle* h);
  *   "cls_tail"        1 (default): in the last ViT block run proj / MLP for the CLS rows only (exact: the
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
  *   "gemm_impl"       0 auto | 128 | 256: LDS-DMA tile width override.  Like every option it belongs to the handle.
- *   "graphs"          1 (default): calls of at most 1024 rows (a few prompts / tiles: ~100 dependent kernels of a few
- *                     microseconds) are captured once and replayed as one hipGraph launch; 0: always launch kernels
+ *   "graphs"          1 (default): launch-bound calls -- keep_encode_image of at most 1024 token rows (5 tiles), keep_encode_text of at most
+ *                     4096 token rows (e.g. 64 prompts x 64 tokens) -- are captured once per shape and replayed as one hipGraph launch (~100
+ *                     dependent kernels of a few microseconds each); 0: always launch kernels
  *   "gemm_skinny_m"   calls with at most this many rows take the small-M split-K GEMM (default 320, 0 never).  The two GEMM paths agree to rounding, each is bit-reproducible
  *   "gemm_splitk_tiles"  a larger call whose 256x256 tiling has fewer tiles than this (default 64, 0 never) is cut into
  *                     K slices with fp32 partials + the same reduce/epilogue kernel (8-16 tiles per call: -16..-26 %)

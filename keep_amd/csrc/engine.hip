@@ -24,6 +24,10 @@
 
 namespace {
 
+// encode_text calls of up to this many token rows (64 prompts x 64 tokens after padding trim: a whole classifier bank chunk) are captured once per shape
+// and replayed as one graph launch: ~90 dependent kernels of 10-25 us whose host-side issue (1.4 ms) otherwise runs next to them
+constexpr int64_t TXT_GRAPH_ROWS = 4096;
+
 // Every entry point runs on the handle's device and puts the caller's current device back (torch keeps its own notion of
 // the current device per thread; changing it behind its back redirects the caller's next allocation).
 struct DevGuard {
@@ -1145,7 +1149,7 @@ int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
     if (prompts > 0 && seq > 0 && h->bert_layers) {
         const int64_t pc = prompts < h->max_prompts ? prompts : h->max_prompts;
         size_t t = align_up(txt_ws_bytes(h, pc, seq, h->any_split()));
-        if (prompts * seq <= SKINNY_MAX_M)        // graph-replayed call: + staged ids / types / mask and outputs
+        if (prompts * seq <= TXT_GRAPH_ROWS)      // graph-replayed call: + staged ids / types / mask and outputs
             t += 3 * align_up((size_t)prompts * seq * 8) + align_up((size_t)prompts * h->bert_H * 4);
         need = t > need ? t : need;
     }
@@ -1175,7 +1179,7 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     hipStream_t s = (hipStream_t)stream;
     const int64_t pc_max = P < h->max_prompts ? P : h->max_prompts;
     const size_t ws_bytes = align_up(txt_ws_bytes(h, pc_max, T, h->any_split()));
-    if (h->use_graphs && !h->prof_mode && P * T <= SKINNY_MAX_M && P <= h->max_prompts) {
+    if (h->use_graphs && !h->prof_mode && P * T <= TXT_GRAPH_ROWS && P <= h->max_prompts) {
         // launch-bound size: stage the caller's tensors into fixed buffers and replay the whole tower as one graph
         const size_t nb = (size_t)P * T * sizeof(int64_t), ob = (size_t)P * h->bert_H * sizeof(float);
         int rc = ensure_arena(h, ws_bytes + 3 * align_up(nb) + align_up(ob));

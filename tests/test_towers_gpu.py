@@ -765,3 +765,30 @@ def test_fp16_range_of_the_qkv_and_hidden_stores(small, text_bank):
         bad[key] = small[key] * factor
         with pytest.raises(ValueError, match=what):
             make_model(bad, "comp")
+
+
+def test_text_graph_replay_covers_a_64_prompt_bank_chunk(small):
+    """encode_text of 64 prompts (valid lengths 8-32 -> run at T = 32: 2048 token rows, the classifier-bank chunk of keep_amd.wsi) is
+    captured once and replayed as one graph launch: same bits as the kernel-by-kernel path, on every replay, for other ids through the
+    same graph, and the token-range flag still works through it."""
+    m = make_model(small, "comp")
+    toks = {k: v.cuda() for k, v in synth_prompts(64, 256, seed=71).items()}
+    m.set_option("graphs", 0)
+    ref = m.encode_text(toks)
+    assert m.last_text_length == 32
+    m.set_option("graphs", 1)
+    for _ in range(3):
+        assert torch.equal(m.encode_text(toks), ref)
+    other = {k: v.cuda() for k, v in synth_prompts(64, 256, seed=72).items()}
+    m.set_option("graphs", 0)
+    ref2 = m.encode_text(other)
+    m.set_option("graphs", 1)
+    assert torch.equal(m.encode_text(other), ref2) and not torch.equal(ref2, ref)
+    with torch.no_grad():
+        want = O.encode_text(small, {k: v.cpu() for k, v in other.items()})
+    assert (ref2.cpu() - want).abs().max() < 5e-6
+    bad = {k: v.clone() for k, v in toks.items()}
+    bad["input_ids"][5, 2] = 10 ** 6
+    m.check_token_ids = True
+    with pytest.raises(IndexError):
+        m.encode_text(bad)
