@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Per-kernel evidence table: for every kernel of one 256-tile encode_image step on ONE internal stream,
+   launches per step, average duration, share of the step, algorithmic work rate against its roofline, matrix-pipe busy share,
+   effective shader clock while it ran, and HBM-side bytes per launch against the algorithmic bytes.
+
+   python tools/kernel_table.py <kernel_stats_single_stream.csv> <pmc_mfma_counter_collection.csv> <hbm_traffic.json> <steps profiled> > table.md
+
+Inputs come from tools/refresh_profiles.sh (rocprofv3 --kernel-trace --stats; --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+GRBM_GUI_ACTIVE in its own pass, also single-stream; FETCH_SIZE / WRITE_SIZE passes reduced by tools/pmc_traffic.py)."""
+import csv, json, re, sys
+from collections import defaultdict
+
+stats_csv, pmc_csv, traffic_json, steps = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+M = 256 * 197                       # rows of a 256-tile step (one lane when streams = 1)
+PEAK_TF, PEAK_HBM = 2516.6, 8000.0
+# kernel-name pattern -> (label, algorithmic FLOP per launch or None, algorithmic bytes per launch or None, roofline)
+G = lambda n, k: 2.0 * M * n * k
+KERNELS = [
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, true>", "qkv GEMM (persistent, bias -> fp16)", G(3072, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "fc1 GEMM (persistent, bias + GELU -> fp16)", G(4096, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>", "proj / fc2 GEMM (persistent, LayerScale + fp32 residual RMW)", None, None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>", "fc1 GEMM + MX-fp4 correction phase", G(4096, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "fc2 GEMM + MX-fp4 correction phase", G(1024, 4096), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, false>", "qkv GEMM, split product (block 0: 3 fp16 passes)", G(3072, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, false>", "proj GEMM, split product (block 0)", G(1024, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 3, false, false>", "patch-embed GEMM, split product", 2.0 * 256 * 196 * 768 * 1024, None, "mfma"),
+    (r"attention_kernel<13, false, 8>", "attention (197 tokens, 16 heads)", 4.0 * 256 * 16 * 197 * 197 * 64, 2.0 * M * 4096, "mfma"),
+    (r"attention_kernel<13, true, 4>", "attention, split product (block 0)", 4.0 * 256 * 16 * 197 * 197 * 64, 4.0 * M * 4096, "mfma"),
+    (r"layernorm_blk_kernel<4, 8>", "LayerNorm (fp32 in, fp16 K-blocked out [+ lo / fp4 planes])", None, 6.0 * M * 1024, "hbm"),
+    (r"im2col_kernel", "im2col (+ cls / pos rows)", None, 256 * 3 * 224 * 224 * 2 + 2 * 2.0 * 256 * 196 * 768, "hbm"),
+]
+
+stats = {}
+for row in csv.DictReader(open(stats_csv)):
+    stats[row["Name"]] = (int(row["Calls"]), float(row["TotalDurationNs"]), float(row["AverageNs"]))
+pmc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for row in csv.DictReader(open(pmc_csv)):
+    a = pmc[row["Kernel_Name"]][row["Counter_Name"]]
+    a[0] += float(row["Counter_Value"]); a[1] += 1
+traffic = json.load(open(traffic_json))
+tr_by_pat = {v["kernel"]: v for v in traffic.values()}
+
+total_ns = sum(t for _, t, _ in stats.values())
+print("| kernel | launches / step | avg µs | % of step | algorithmic rate | frac of roofline | matrix pipe busy | eff. clock (MHz) | HBM-side bytes / launch (÷ algorithmic) |")
+print("|---|---|---|---|---|---|---|---|---|")
+seen = 0.0
+for pat, label, flop, abytes, roof in KERNELS:
+    hit = [(n, v) for n, v in stats.items() if pat in n]
+    if not hit:
+        continue
+    name, (calls, tot, avg) = hit[0]
+    seen += tot
+    rate = frac = "—"
+    if roof == "mfma" and flop:
+        tf = flop / avg / 1e3
+        rate, frac = f"{tf:.0f} TFLOP/s", f"{tf / PEAK_TF:.3f}"
+    elif roof == "hbm" and abytes:
+        gb = abytes / avg
+        rate, frac = f"{gb:.0f} GB/s", f"{gb / PEAK_HBM:.3f}"
+    c = next((v for n, v in pmc.items() if pat in n), None)
+    busy = clk = "—"
+    if c and c.get("GRBM_GUI_ACTIVE") and c["GRBM_GUI_ACTIVE"][1]:
+        gui = c["GRBM_GUI_ACTIVE"][0] / c["GRBM_GUI_ACTIVE"][1]
+        mf = c["SQ_VALU_MFMA_BUSY_CYCLES"][0] / max(c["SQ_VALU_MFMA_BUSY_CYCLES"][1], 1) if "SQ_VALU_MFMA_BUSY_CYCLES" in c else 0.0
+        busy = f"{mf / (gui * 1024):.2f}"                         # busy SIMD-cycles / (kernel cycles x 1024 SIMDs)
+        clk = f"{gui / avg * 1e3:.0f}"                            # cycles per ns x 1000
+    t = tr_by_pat.get(pat)
+    tb = "—"
+    if t:
+        tb = f"{t['bytes_per_launch'] / 1e6:.0f} MB" + (f" ({t['traffic_over_algorithmic']}x)" if "traffic_over_algorithmic" in t else "")
+    print(f"| `{label}` | {calls / steps:.1f} | {avg / 1e3:.1f} | {100 * tot / total_ns:.1f} | {rate} | {frac} | {busy} | {clk} | {tb} |")
+print(f"| everything else | | | {100 * (total_ns - seen) / total_ns:.1f} | | | | | |")
+print(f"\nstep = {total_ns / steps / 1e6:.2f} ms of kernel time on one stream ({steps:.0f} steps profiled); peaks: {PEAK_TF} TFLOP/s dense fp16 at 2.4 GHz, {PEAK_HBM:.0f} GB/s HBM.")
+print("`matrix pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); `eff. clock` = GRBM_GUI_ACTIVE / duration (pmc pass). "
+      "traffic rows are measured on the two-lane run (128-tile launches: the ratio is what matters).")

@@ -22,7 +22,15 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
     > /dev/null 2> "$OUT/pmc_MFMA.log"
 cd "$REPO"
 python tools/pmc_summary.py "$(find /tmp/pmc_MFMA -name '*counter_collection.csv' | head -1)" > "$OUT/mfma_busy.txt" 2>&1
+# the same counters on ONE internal stream (clean per-kernel attribution) -> the per-kernel table
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_MFMA1 --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown --no-configs --no-sustained --opt streams=1 \
+    > /dev/null 2> "$OUT/pmc_MFMA1.log"
+cd "$REPO"
 sha256sum keep_amd/libkeep_hip.so | cut -c1-16 > "$OUT/lib_sha16.txt"
 python tools/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" \
                             "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" > /dev/null
+python tools/kernel_table.py "$OUT/kernel_stats_single_stream.csv" "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" 13 > "$OUT/per_kernel_table.md" 2> "$OUT/per_kernel_table.err"
+python tools/clock_check.py > "$OUT/clock_under_load.txt" 2>&1
+cat "$OUT/per_kernel_table.md"
 head -c 600 "$OUT/bench.json"; echo; head -5 "$OUT/kernel_stats.csv"; cat "$OUT/hbm_traffic.json" | head -12
