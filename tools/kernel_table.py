@@ -34,9 +34,12 @@ stats = {}
 for row in csv.DictReader(open(stats_csv)):
     stats[row["Name"]] = (int(row["Calls"]), float(row["TotalDurationNs"]), float(row["AverageNs"]))
 pmc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+pmc_dur = defaultdict(dict)          # kernel -> {dispatch id: ns}: durations of the SAME (counter-collecting) run, when the CSV carries timestamps
 for row in csv.DictReader(open(pmc_csv)):
     a = pmc[row["Kernel_Name"]][row["Counter_Name"]]
     a[0] += float(row["Counter_Value"]); a[1] += 1
+    if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+        pmc_dur[row["Kernel_Name"]][row.get("Dispatch_Id", len(pmc_dur[row["Kernel_Name"]]))] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
 traffic = json.load(open(traffic_json))
 tr_by_pat = {v["kernel"]: v for v in traffic.values()}
 
@@ -57,13 +60,15 @@ for pat, label, flop, abytes, roof in KERNELS:
     elif roof == "hbm" and abytes:
         gb = abytes / avg
         rate, frac = f"{gb:.0f} GB/s", f"{gb / PEAK_HBM:.3f}"
-    c = next((v for n, v in pmc.items() if pat in n), None)
+    kn, c = next(((n, v) for n, v in pmc.items() if pat in n), (None, None))
     busy = clk = "—"
     if c and c.get("GRBM_GUI_ACTIVE") and c["GRBM_GUI_ACTIVE"][1]:
-        gui = c["GRBM_GUI_ACTIVE"][0] / c["GRBM_GUI_ACTIVE"][1]
+        gui = c["GRBM_GUI_ACTIVE"][0] / c["GRBM_GUI_ACTIVE"][1] / 8.0     # the counter is summed over the 8 XCDs (an idle-chip probe kernel reads 8 x 2.4 GHz x its duration)
         mf = c["SQ_VALU_MFMA_BUSY_CYCLES"][0] / max(c["SQ_VALU_MFMA_BUSY_CYCLES"][1], 1) if "SQ_VALU_MFMA_BUSY_CYCLES" in c else 0.0
         busy = f"{mf / (gui * 1024):.2f}"                         # busy SIMD-cycles / (kernel cycles x 1024 SIMDs)
-        clk = f"{gui / avg * 1e3:.0f}"                            # cycles per ns x 1000
+        d = pmc_dur.get(kn)
+        dur = sum(d.values()) / len(d) if d else avg             # same-run duration when the CSV has timestamps, else the stats run's
+        clk = f"{gui / dur * 1e3:.0f}" + ("" if d else "*")
     t = tr_by_pat.get(pat)
     tb = "—"
     if t:
@@ -71,5 +76,6 @@ for pat, label, flop, abytes, roof in KERNELS:
     print(f"| `{label}` | {calls / steps:.1f} | {avg / 1e3:.1f} | {100 * tot / total_ns:.1f} | {rate} | {frac} | {busy} | {clk} | {tb} |")
 print(f"| everything else | | | {100 * (total_ns - seen) / total_ns:.1f} | | | | | |")
 print(f"\nstep = {total_ns / steps / 1e6:.2f} ms of kernel time on one stream ({steps:.0f} steps profiled); peaks: {PEAK_TF} TFLOP/s dense fp16 at 2.4 GHz, {PEAK_HBM:.0f} GB/s HBM.")
-print("`matrix pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); `eff. clock` = GRBM_GUI_ACTIVE / duration (pmc pass). "
+print("`matrix pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); `eff. clock` = GRBM_GUI_ACTIVE / 8 / duration of the same dispatches "
+      "(* = duration taken from the kernel-trace run: the counter CSV had no timestamps); counter-collecting runs serialise kernels and clock a little lower than plain ones. "
       "traffic rows are measured on the two-lane run (128-tile launches: the ratio is what matters).")
