@@ -20,6 +20,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // final normalisation kernel raises the handle's "non-finite features" flag (the reference computes in fp32 and would not overflow;
 // clamping would return plausible garbage instead).
 __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
+    // x is pinned as ONE materialised fp32 value.  Without this hipcc (-ffp-contract=fast) folds the multiply / fma that produced x into
+    // v_fma_mixlo_f16 for the hi that feeds `lo` (exact product rounded once to fp16) while the STORED hi is v_cvt(v_mul) (rounded twice):
+    // the two disagree by an fp16 ulp on a few values per thousand, and hi + lo is then 1e-3 off instead of 2^-22 (found by the split-attention
+    // operator test when the saturating clamp, which happened to block the pattern, was removed).
+    asm("" : "+v"(x));
     hi = (f16)x;
     lo = (f16)(x - (float)hi);
 }

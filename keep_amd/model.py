@@ -253,13 +253,13 @@ class KEEPModel:
 
     @torch.no_grad()
     def calibrate(self, n_tiles: int = 256, target: float = CALIBRATION_TARGET, tiles: Optional[torch.Tensor] = None,
-                  text_features: Optional[torch.Tensor] = None, seed: int = 20250929) -> Optional[dict]:
+                  text_features: Optional[torch.Tensor] = None, seed: int = 20250929, tolerance: float = TOLERANCE) -> Optional[dict]:
         """Pick the 'comp' setting for THESE weights instead of trusting the one tuned on the synthetic default family.
 
         A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded
         once with split products (the engine's fp32-class arithmetic, ~5e-7 from the fp32 reference) and then with each rung of
         ``COMP_LADDER`` from the cheapest up; the first rung whose worst |cos - cos_split| over probe tiles x prompts is <= ``target``
-        (and whose rms x 5.2 is inside the 1e-4 tolerance) is kept (``comp_full_blocks`` / ``comp_mlp_blocks`` options).  The prompts are ``text_features`` ([P,768] unit rows; default:
+        (and whose rms x 5.2 is inside ``tolerance``, 1e-4) is kept (``comp_full_blocks`` / ``comp_mlp_blocks`` options).  The prompts are ``text_features`` ([P,768] unit rows; default:
         64 seeded prompts through the loaded text tower, or 64 seeded random unit vectors for an image-only engine).  If even the last
         rung misses, the engine switches to 'strict'.  Non-finite probe features (an activation beyond the fp16 range) raise
         FloatingPointError.  Returns and stores ``self.calibration``."""
@@ -299,7 +299,7 @@ class KEEPModel:
                 d = (self.encode_image(tiles) @ bank - ref).abs()
                 err, rms = float(d.max()), float(d.pow(2).mean().sqrt())
                 tried.append({"comp_full_blocks": full, "comp_mlp_blocks": mlp, "max_abs_dcos": float(f"{err:.3e}"), "rms_dcos": float(f"{rms:.3e}")})
-                if err <= target and rms * CALIBRATION_SIGMAS <= TOLERANCE:      # (NaN compares False: falls through to the next rung)
+                if err <= target and rms * CALIBRATION_SIGMAS <= tolerance:      # (NaN compares False: falls through to the next rung)
                     chosen = (full, mlp)
                     break
             if chosen is None:
@@ -309,7 +309,7 @@ class KEEPModel:
             self.auto_calibrate = was
         self.calibration = {"precision": "comp" if chosen else "strict", "comp_full_blocks": chosen[0] if chosen else None,
                             "comp_mlp_blocks": chosen[1] if chosen else None, "target_max_abs_dcos": target,
-                            "target_rms_dcos": float(f"{TOLERANCE / CALIBRATION_SIGMAS:.3e}"),
+                            "target_rms_dcos": float(f"{tolerance / CALIBRATION_SIGMAS:.3e}"),
                             "probe": f"{tiles.shape[0]} tiles x {bank.shape[1]} prompts vs the split-product arithmetic", "tried": tried}
         return self.calibration
 

@@ -707,7 +707,7 @@ def test_calibrate_walks_the_ladder_and_reports(small):
     assert (m.encode_image(x).cpu() - ref).abs().max() < 5e-6
     # a generous target keeps the first rung; explicit probe tiles and prompts are accepted
     m.set_precision("comp")
-    cal = m.calibrate(tiles=synth_tiles(40, seed=9).to(torch.bfloat16), text_features=torch.nn.functional.normalize(torch.randn(7, 768), dim=-1), target=1e-3)
+    cal = m.calibrate(tiles=synth_tiles(40, seed=9).to(torch.bfloat16), text_features=torch.nn.functional.normalize(torch.randn(7, 768), dim=-1), target=1e-3, tolerance=1e-2)
     assert cal["precision"] == "comp" and len(cal["tried"]) == 1 and "40 tiles x 7 prompts" in cal["probe"]
     fp = make_model(small, "fp16")
     assert fp.calibration is None and fp.calibrate() is None            # only the compensated mode has something to choose
