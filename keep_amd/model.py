@@ -31,8 +31,9 @@ DEFAULT_PRECISION = "comp"     # the mode that meets the reference tolerance (co
 # carry the MX-fp4 correction terms.  calibrate() walks up this ladder until the probe's worst cosine error is inside its target.
 COMP_LADDER = ((0, 0), (0, 4), (1, 4), (1, 6), (1, 8), (1, 10), (1, 12), (2, 12), (2, 16), (2, 24), (4, 24), (8, 24), (24, 24))
 CALIBRATION_TARGET = 0.7e-4    # of the 1e-4 tolerance: head-room for the larger population of a real slide and for other tiles
-CALIBRATION_SIGMAS = 5.2       # ... and rms x 5.2 (the expected maximum of ~1e6 cosines) must stay inside the tolerance as well: the probe's own maximum
-                               # is taken over 256 tiles, and errors are correlated per tile (measured: probe max 5.8e-5 -> 8.7e-5 over config 3's 4096 tiles)
+CALIBRATION_SIGMAS = 4.6       # ... and rms x 4.6 must stay inside the tolerance as well: the probe's own maximum is taken over 256 tiles and errors are correlated
+                               # per tile (measured: probe max 5.8e-5 -> 8.7e-5 over config 3's 4096 tiles); 4.6 = max / rms measured over config 3's 262 144
+                               # cosines (8.7e-5 / 1.9e-5; 7.9e-5 / 1.8e-5 at the 1 / 8 setting)
 TOLERANCE = 1e-4
 
 
@@ -259,7 +260,7 @@ class KEEPModel:
         A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded
         once with split products (the engine's fp32-class arithmetic, ~5e-7 from the fp32 reference) and then with each rung of
         ``COMP_LADDER`` from the cheapest up; the first rung whose worst |cos - cos_split| over probe tiles x prompts is <= ``target``
-        (and whose rms x 5.2 is inside ``tolerance``, 1e-4) is kept (``comp_full_blocks`` / ``comp_mlp_blocks`` options).  The prompts are ``text_features`` ([P,768] unit rows; default:
+        (and whose rms x 4.6 is inside ``tolerance``, 1e-4) is kept (``comp_full_blocks`` / ``comp_mlp_blocks`` options).  The prompts are ``text_features`` ([P,768] unit rows; default:
         64 seeded prompts through the loaded text tower, or 64 seeded random unit vectors for an image-only engine).  If even the last
         rung misses, the engine switches to 'strict'.  Non-finite probe features (an activation beyond the fp16 range) raise
         FloatingPointError.  Returns and stores ``self.calibration``."""
