@@ -570,7 +570,7 @@ void launch_unblockify_f32(const f16* hi, const f16* lo, float* out, int M, int 
 
 void launch_weight_stats(const float* w, int64_t n, float* stats2, hipStream_t s) {
     (void)hipMemsetAsync(stats2, 0, 2 * sizeof(float), s);
-    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((n + 255) / 256); if (blocks > 256) blocks = 256;      // one atomic pair per wave: keep the count low (2048 blocks: 200 us per tensor on the atomics alone)
     hipLaunchKernelGGL(weight_stats_kernel, dim3(blocks), dim3(256), 0, s, w, n, (unsigned*)stats2, stats2 + 1);
 }
 void launch_l2norm_rows(float* x, int rows, int D, float eps, hipStream_t s, int* err_flag) {
