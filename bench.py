@@ -239,8 +239,11 @@ def main():
     torch.set_num_threads(min(usable_cpus(), 16))
     shape = KEEPShape()
     want_configs = rank == 0 and world == 1 and not args.no_configs      # the config-3 parity / c3 / c5 legs belong to the 1-GPU line; scaling runs stay lean
-    sd = synth_state_dict(shape, seed=0, text=want_configs)          # identical image-tower weights on every rank; rank 0 adds the text tower for config 3
-    model = KEEPModel(shape, precision=args.precision, towers=("image", "text") if want_configs else ("image",))
+    # identical weights on every rank, BOTH towers everywhere: the load-time calibration measures its cosines against prompts through the loaded text
+    # tower (an image-only engine falls back to random unit vectors, a harsher yardstick that picks a slower setting) -- every rank of every world
+    # size must run the same setting for the scaling figures to compare like with like
+    sd = synth_state_dict(shape, seed=0, text=True)
+    model = KEEPModel(shape, precision=args.precision, towers=("image", "text"))
     model.precision_name = args.precision
     model.load_state_dict(sd, strict=True)
     model.to(dev).eval()
