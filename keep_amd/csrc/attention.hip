@@ -130,9 +130,6 @@ void attention_kernel(AttnParams p) {
 
     long long t_start = 0, t_staged = 0;
     if (p.dbg) t_start = __builtin_readcyclecounter();
-    if (p.stagger > 0 && (int)blockIdx.x >= p.stagger_lo && (int)blockIdx.x < p.stagger_hi) {
-        for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);       // s_sleep n: ~64 n cycles
-    }
     stage_kv<NT, ATT_THREADS>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
     if (SPLIT) stage_kv<NT, ATT_THREADS>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
     for (int k = tid; k < NKP; k += ATT_THREADS) {
@@ -353,12 +350,6 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
 #endif
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
-    p.stagger = p.tune ? p.tune->attn_stagger : 0;
-    if (p.stagger > 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        p.stagger_lo = cus; p.stagger_hi = 2 * cus;
-    }
     // 32-bit lane offsets inside the kernel: qkv rows of one (batch) slice and the whole output plane (padded to 256 rows) stay below 2^31 elements
     if ((int64_t)p.ntok * 3 * p.heads * HD >= (1ll << 31) || ((int64_t)p.batch * p.ntok + 255) / 256 * 256 * p.heads * HD >= (1ll << 31)) return -1;
     if (p.split) {

@@ -73,8 +73,6 @@ struct KeepTune {
     int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
     int ln_impl = 1;             // 1: LDS-transposed blk stores; 0: per-row stores
     int attn_waves = 8;          // wavefronts per attention workgroup for 13/16-tile sequences (4 or 8)
-    int attn_stagger = 0;        // experiment: the second workgroup of every CU (blocks CUs .. 2*CUs-1) starts this many x 64 cycles late, so that the two
-                                 // co-resident workgroups alternate staging and compute instead of running both phases in lockstep
     int gemm_persistent = 1;     // 1: plain 256x256 GEMMs with more tiles than CUs run as one workgroup per CU walking the tile list, the next tile's
                                  //    first three K steps prefetched under the epilogue (0: one tile per workgroup; n > 1: n workgroups, experiments)
     int gemm_ablate = 0;         // diagnostics (KEEP_DIAGNOSTICS builds only)
@@ -147,7 +145,6 @@ struct AttnParams {
     int split;                            // 0/1
     float scale;                          // 1/sqrt(64)
     long long* dbg;                       // diagnostics: per-workgroup [start, staged, end] shader clocks (tools/attn_timeline.py)
-    int stagger, stagger_lo, stagger_hi;  // blocks [stagger_lo, stagger_hi) sleep `stagger` x 64 cycles before staging (KeepTune::attn_stagger)
     const KeepTune* tune;
 };
 int launch_attention(const AttnParams& p, hipStream_t s);   // returns 0 or -1 (unsupported ntok)

@@ -1087,7 +1087,6 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
     else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); t.ln_impl = v; }
-    else if (n == "attn_stagger") { if (v < 0 || v > 1 << 20) return h->fail(KEEP_EINVAL, "attn_stagger must be 0..2^20"); t.attn_stagger = v; }
     else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); t.attn_waves = v; }
     else if (n == "gemm_impl") {
         bool ok = v == 0 || v == 128 || v == 256;
@@ -1128,7 +1127,6 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "gemm_persistent") return t.gemm_persistent;
     if (n == "ln_impl") return t.ln_impl;
     if (n == "attn_waves") return t.attn_waves;
-    if (n == "attn_stagger") return t.attn_stagger;
     if (n == "lane_skew") return h->lane_skew;
     if (n == "lane0_permille") return h->lane0_permille;
     if (n == "cls_tail") return h->cls_tail;
