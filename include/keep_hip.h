@@ -74,6 +74,10 @@ const char* keep_version(void);
 int keep_create(int device_id, keep_handle** out);
 int keep_destroy(keep_handle* h);
 const char* keep_last_error(keep_handle* h);
+/* Notes collected by keep_load_tensor since the last call ('\n'-separated, "" if none; the call clears them): e.g. a GEMM weight whose rms is so
+ * small that its entries fall into fp16 subnormals.  Such a tensor LOADS (torch's load_state_dict, keep_inference.py:83, has no such notion);
+ * the Python binding turns each line into a warnings.warn.  The pointer is valid until the calling thread's next keep_load_warnings call. */
+const char* keep_load_warnings(keep_handle* h);
 
 /* ---- weights ----------------------------------------------------------------------------------
  * Replaces: `model.load_state_dict(state_dict, strict=True)`  (quick_start/keep_inference.py:82-83).

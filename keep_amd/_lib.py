@@ -27,6 +27,7 @@ SIGNATURES = {
     "keep_create": (_i32, [_i32, C.POINTER(_vp)]),
     "keep_destroy": (_i32, [_vp]),
     "keep_last_error": (C.c_char_p, [_vp]),
+    "keep_load_warnings": (C.c_char_p, [_vp]),
     "keep_load_tensor": (_i32, [_vp, C.c_char_p, _vp, _i32, C.POINTER(_i64), _i32]),
     "keep_finalize_weights": (_i32, [_vp]),
     "keep_vit_depth": (_i32, [_vp]),

@@ -48,6 +48,7 @@ struct WTensor {
     f16* lo = nullptr;
     unsigned char* q = nullptr;   // MX-fp4 side planes of (hi, lo) and their scales (quant4.h); K % 128 == 0 weights only
     unsigned char* sc = nullptr;
+    float prescale = 1.f;     // the planes hold prescale * W (a power of two; proj / fc2 of the image tower only): folded back through LayerScale and bias at finalize
 };
 
 enum Tag {
@@ -74,6 +75,7 @@ struct BertLayer {
 struct keep_handle {
     int device = 0;
     std::string err;
+    std::string load_warnings;   // '\n'-separated notes of keep_load_tensor calls (a weight the fp16 planes resolve poorly); read and cleared by keep_load_warnings
     std::map<std::string, WTensor> w;
     bool finalized = false;
 
@@ -82,6 +84,7 @@ struct keep_handle {
     int bert_layers = 0, bert_H = 0, bert_heads = 0, bert_F = 0, bert_vocab = 0, bert_maxpos = 0, bert_types = 0;
     std::vector<VitBlock> vblocks;
     std::vector<BertLayer> blayers;
+    std::vector<float*> owned_vecs;   // LayerScale / bias vectors re-derived for pre-scaled weights (finalize_vit)
 
     // options
     KeepTune tune;               // kernel selection (travels in the launch parameter blocks; nothing is process-wide)
@@ -624,8 +627,7 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
         const int64_t n = t.shape[0], k = t.numel / t.shape[0];
         if (n % 256 || k % 32) return h->fail(KEEP_EUNSUPPORTED, "%s: [%lld,%lld] is not tileable (rows %% 256, cols %% 32)", key.c_str(), (long long)n, (long long)k);
         // The GEMM operand planes are fp16: 11 significant bits between 6.1e-5 and 65504, fewer below (subnormals), none above.  A weight whose
-        // entries sit outside that window would be resolved worse than the error budget assumes -- and the split-product mode, which calibrate()
-        // measures against, would lose the same bits, so nothing downstream could notice.  Refuse it here instead.
+        // entries sit above that window cannot be represented at all: refused.  (Below it: see the warning further down.)
         {
             float host[2] = {0.f, 0.f};
             HIPCHK(h, hipMemsetAsync(h->err_flag + 2, 0, 2 * sizeof(float), nullptr));
@@ -633,8 +635,30 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
             HIPCHK(h, hipMemcpy(host, h->err_flag + 2, sizeof host, hipMemcpyDeviceToHost));
             const double rms = sqrt((double)host[1] / (double)t.numel);
             if (!(host[0] <= 6.0e4f)) return h->fail(KEEP_EUNSUPPORTED, "%s: max |w| = %g does not fit the fp16 operand planes (65504) or is not finite", key.c_str(), (double)host[0]);
-            if (rms > 0.0 && rms < 2.5e-4) return h->fail(KEEP_EUNSUPPORTED, "%s: rms %g is below what the fp16 operand planes resolve (entries fall into fp16 subnormals); "
-                                                          "rescale the checkpoint or use the fp32 reference path", key.c_str(), rms);
+            // A weight far below fp16's normal range (a projection whose magnitude lives in its LayerScale, a pruned or dead layer) still loads, as it
+            // does in the reference.  proj / fc2 of the image tower are pre-scaled by a power of two into the window -- exact: their epilogue is
+            // ls * (acc + bias), and finalize_vit hands it ls / 2^k and bias * 2^k -- any other weight keeps its entries (they fall into fp16
+            // subnormals and lose RELATIVE precision; what such a layer adds to the stream is as small as the layer) and the caller is told.
+            if (rms > 0.0 && rms < 2.5e-4) {
+                const bool foldable = starts_with(key, "visual.blocks.") && (key.find(".attn.proj.weight") != std::string::npos || key.find(".mlp.fc2.weight") != std::string::npos);
+                char buf[512];
+                if (foldable && t.numel < (1ll << 31)) {
+                    float k2 = exp2f(roundf(log2f(0.02f / (float)rms)));
+                    while (host[0] * k2 > 3.0e4f) k2 *= 0.5f;
+                    t.prescale = k2;
+                    snprintf(buf, sizeof buf, "%s: rms %g is below fp16's normal range; stored as 2^%d * W with LayerScale / bias adjusted (exact)", key.c_str(), rms, (int)log2f(k2));
+                } else {
+                    snprintf(buf, sizeof buf, "%s: rms %g is below what the fp16 operand planes resolve with 11 bits (entries fall into fp16 subnormals): "
+                                              "this layer's products carry fewer significant bits than the error budget assumes", key.c_str(), rms);
+                }
+                h->load_warnings += (h->load_warnings.empty() ? "" : "\n") + std::string(buf);
+            }
+        }
+        float* scaled = nullptr;
+        if (t.prescale != 1.f) {
+            HIPCHK(h, hipMalloc(&scaled, t.numel * sizeof(float)));
+            launch_scale_vec(dev, (int)t.numel, t.prescale, scaled, nullptr);
+            dev = scaled;
         }
         HIPCHK(h, hipMalloc(&t.hi, t.numel * sizeof(f16)));
         HIPCHK(h, hipMalloc(&t.lo, t.numel * sizeof(f16)));
@@ -647,6 +671,7 @@ int store_tensor(keep_handle* h, const std::string& key, const float* dev, const
             launch_split_blockify(dev, t.hi, t.lo, (int)n, (int)k, nullptr);
         }
         HIPCHK(h, hipStreamSynchronize(nullptr));
+        if (scaled) (void)hipFree(scaled);
     } else {
         const size_t bytes = (size_t)(t.numel > 4 ? t.numel : 4) * sizeof(float);
         HIPCHK(h, hipMalloc(&t.f32, bytes));
@@ -680,6 +705,8 @@ const WTensor* need_mat(keep_handle* h, const std::string& key, int64_t n, int64
 
 int finalize_vit(keep_handle* h) {
     h->vblocks.clear(); h->vit_depth = 0;
+    for (float* v : h->owned_vecs) (void)hipFree(v);
+    h->owned_vecs.clear();
     const WTensor* pe = find(h, "visual.patch_embed.proj.weight");
     if (!pe) {
         for (auto& kv : h->w) if (starts_with(kv.first, "visual")) return h->fail(KEEP_EKEY, "missing key visual.patch_embed.proj.weight");
@@ -721,6 +748,20 @@ int finalize_vit(keep_handle* h) {
     }
     if (!miss.empty()) return h->fail(KEEP_EKEY, "missing or mis-shaped key(s): %s", miss.c_str());
     if (F % 256 || D % 256 || PJ % 16) return h->fail(KEEP_EUNSUPPORTED, "ViT dims not tileable");
+    // pre-scaled proj / fc2 planes (store_tensor): ls * (acc + b) with acc = 2^k * (a . w)  ->  (ls / 2^k) * (acc + 2^k * b), exact in fp32
+    auto rescaled = [&](const float* v, float f) -> const float* {
+        float* o = nullptr;
+        if (hipMalloc(&o, D * sizeof(float)) != hipSuccess) return nullptr;
+        launch_scale_vec(v, (int)D, f, o, nullptr);
+        h->owned_vecs.push_back(o);
+        return o;
+    };
+    for (auto& b : h->vblocks) {
+        if (b.proj->prescale != 1.f) { b.ls1 = rescaled(b.ls1, 1.f / b.proj->prescale); b.proj_b = rescaled(b.proj_b, b.proj->prescale); }
+        if (b.fc2->prescale != 1.f) { b.ls2 = rescaled(b.ls2, 1.f / b.fc2->prescale); b.fc2_b = rescaled(b.fc2_b, b.fc2->prescale); }
+        if (!b.ls1 || !b.proj_b || !b.ls2 || !b.fc2_b) return h->fail(KEEP_EHIP, "hipMalloc failed for a rescaled LayerScale / bias vector");
+    }
+    HIPCHK(h, hipStreamSynchronize(nullptr));
     h->vit_has_q = true;
     for (auto& b : h->vblocks) if (!b.fc1->q || !b.fc2->q) h->vit_has_q = false;
     h->vit_depth = depth; h->vit_D = (int)D; h->vit_heads = (int)(D / 64); h->vit_F = (int)F; h->proj_dim = (int)PJ;
@@ -1005,6 +1046,7 @@ int keep_destroy(keep_handle* h) {
     for (auto& kv : h->w) { if (kv.second.f32) hipFree(kv.second.f32); if (kv.second.hi) hipFree(kv.second.hi); if (kv.second.lo) hipFree(kv.second.lo);
                             if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); }
     if (h->tune.dbg) hipFree(h->tune.dbg);
+    for (float* v : h->owned_vecs) hipFree(v);
     for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
     drop_graphs(h);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
@@ -1018,6 +1060,14 @@ int keep_destroy(keep_handle* h) {
 }
 
 const char* keep_last_error(keep_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+const char* keep_load_warnings(keep_handle* h) {
+    if (!h) return "";
+    static thread_local std::string out;
+    out.swap(h->load_warnings);
+    h->load_warnings.clear();
+    return out.c_str();
+}
 
 int keep_load_tensor(keep_handle* h, const char* key, const float* data, int ndim, const int64_t* shape, int on_device) {
     if (!h || !key || !data || ndim < 0 || ndim > 8) return KEEP_EINVAL;

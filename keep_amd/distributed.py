@@ -191,3 +191,18 @@ def timed_steps(step: Callable[[], None], n_steps: int, exchange: StepExchange) 
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=exchange.group)
         el = float(t.item())
     return el
+
+
+def assert_same_setting(values, what: str = "precision setting", device=None, group=None) -> list:
+    """Every rank must run the SAME engine setting for a multi-rank figure to mean anything (each rank calibrates on its own at load):
+    all-gather ``values`` (a short sequence of numbers) and raise on every rank if any rank differs.  Returns the gathered rows."""
+    row = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [row.tolist()]
+    world = dist.get_world_size(group)
+    rows = [torch.empty_like(row) for _ in range(world)]
+    dist.all_gather(rows, row, group=group)
+    got = [r.tolist() for r in rows]
+    if any(r != got[0] for r in got):
+        raise RuntimeError(f"ranks disagree on the {what}: " + "; ".join(f"rank {i}: {r}" for i, r in enumerate(got)))
+    return got

@@ -30,11 +30,20 @@ DEFAULT_PRECISION = "comp"     # the mode that meets the reference tolerance (co
 # 'comp' settings in order of cost: (comp_full_blocks, comp_mlp_blocks) = blocks whose attention side runs split products / whose MLP GEMMs
 # carry the MX-fp4 correction terms.  calibrate() walks up this ladder until the probe's worst cosine error is inside its target.
 COMP_LADDER = ((0, 0), (0, 4), (1, 4), (1, 6), (1, 8), (1, 10), (1, 12), (2, 12), (2, 16), (2, 24), (4, 24), (8, 24), (24, 24))
-CALIBRATION_TARGET = 0.7e-4    # of the 1e-4 tolerance: head-room for the larger population of a real slide and for other tiles
-CALIBRATION_SIGMAS = 4.6       # ... and rms x 4.6 must stay inside the tolerance as well: the probe's own maximum is taken over 256 tiles and errors are correlated
-                               # per tile (measured: probe max 5.8e-5 -> 8.7e-5 over config 3's 4096 tiles); 4.6 = max / rms measured over config 3's 262 144
-                               # cosines (8.7e-5 / 1.9e-5; 7.9e-5 / 1.8e-5 at the 1 / 8 setting)
+# calibrate() keeps the cheapest rung whose probe statistics predict a worst cosine error inside TOLERANCE over the POPULATION the model will
+# be used on (tiles x distinct prompts): rms x expected_max_sigmas(population) <= TOLERANCE, and the probe's own maximum scaled the same way.
+# Measured: config 3 (262 144 cosines) max / rms = 4.4-4.6 against expected_max_sigmas = 4.63; 100 000 tiles x 64 prompts: see bench.py c4.
+CALIBRATION_POPULATION = 100_000 * 264      # BASELINE config 4: a 100 000-tile slide against the 264 distinct prompt strings of the RCC bank
 TOLERANCE = 1e-4
+
+
+def expected_max_sigmas(n: float) -> float:
+    """E[max |x_i|] / sigma over n independent N(0, sigma) samples (extreme-value asymptote of 2n one-sided samples): the factor between the
+    rms of the cosine errors and the worst one to expect in a population of n cosines.  16 384 -> 4.03, 262 144 -> 4.63, 6.4e6 -> 5.26,
+    2.6e7 -> 5.51, 7.1e8 -> 6.06."""
+    n2 = 2.0 * max(float(n), 2.0)
+    a = math.sqrt(2.0 * math.log(n2))
+    return a - (math.log(math.log(n2)) + math.log(4.0 * math.pi)) / (2.0 * a)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -80,7 +89,7 @@ class KEEPModel:
         self._pending_token_checks = []   # [(pinned int32 flag, event)] in issue order; the device flag is sticky, so none can be lost
         self._flag_pool = []              # pinned buffers are recycled only after their copy has landed
         # load_state_dict on a GPU ends with calibrate(): the cheapest 'comp' setting whose worst cosine error on a seeded probe batch
-        # (against the engine's own split-product arithmetic) stays inside CALIBRATION_TARGET.  KEEP_CALIBRATE=0 / auto_calibrate=False: keep the
+        # (against the engine's own split-product arithmetic) predicts a worst error inside the tolerance over CALIBRATION_POPULATION cosines.  KEEP_CALIBRATE=0 / auto_calibrate=False: keep the
         # built-in default (1, 8), which was chosen on ONE synthetic weight family.
         self.auto_calibrate = os.environ.get("KEEP_CALIBRATE", "1") != "0"
         self.calibration: Optional[dict] = None
@@ -193,6 +202,11 @@ class KEEPModel:
                 _lib.check(h, rc, key)
         if errors:
             raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\t" + "\n\t".join(errors))
+        notes = lib.keep_load_warnings(h).decode()
+        if notes:
+            import warnings
+            for line in notes.split("\n"):
+                warnings.warn(line, RuntimeWarning, stacklevel=3)
         rc = lib.keep_finalize_weights(h)
         if rc == _lib.KEEP_EKEY:
             raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\t" + lib.keep_last_error(h).decode())
@@ -253,17 +267,21 @@ class KEEPModel:
         return self
 
     @torch.no_grad()
-    def calibrate(self, n_tiles: int = 256, target: float = CALIBRATION_TARGET, tiles: Optional[torch.Tensor] = None,
+    def calibrate(self, n_tiles: int = 256, population: Optional[float] = None, tiles: Optional[torch.Tensor] = None,
                   text_features: Optional[torch.Tensor] = None, seed: int = 20250929, tolerance: float = TOLERANCE) -> Optional[dict]:
-        """Pick the 'comp' setting for THESE weights instead of trusting the one tuned on the synthetic default family.
+        """Pick the 'comp' setting for THESE weights and for the population the model will be used on.
 
         A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded
         once with split products (the engine's fp32-class arithmetic, ~5e-7 from the fp32 reference) and then with each rung of
-        ``COMP_LADDER`` from the cheapest up; the first rung whose worst |cos - cos_split| over probe tiles x prompts is <= ``target``
-        (and whose rms x 4.6 is inside ``tolerance``, 1e-4) is kept (``comp_full_blocks`` / ``comp_mlp_blocks`` options).  The prompts are ``text_features`` ([P,768] unit rows; default:
-        64 seeded prompts through the loaded text tower, or 64 seeded random unit vectors for an image-only engine).  If even the last
-        rung misses, the engine switches to 'strict'.  Non-finite probe features (an activation beyond the fp16 range) raise
-        FloatingPointError.  Returns and stores ``self.calibration``."""
+        ``COMP_LADDER`` from the cheapest up.  Kept: the first rung whose cosine errors over probe tiles x prompts predict a worst
+        error <= ``tolerance`` (1e-4) over ``population`` cosines (tiles x distinct prompts the caller will compare; default
+        ``CALIBRATION_POPULATION`` = a 100 000-tile slide x the 264 distinct prompts of the RCC bank, BASELINE config 4):
+        ``rms x expected_max_sigmas(population) <= tolerance`` and ``probe max x sigmas(population) / sigmas(probe size) <= tolerance``.
+        The prompts are ``text_features`` ([P,768] unit rows -- pass the caller's own bank to calibrate against it; default: 64 seeded
+        prompts through the loaded text tower, or 64 seeded random unit vectors for an image-only engine, a harsher yardstick).  If even
+        the last rung misses, the engine switches to 'strict'.  Non-finite probe features (an activation beyond the fp16 range) raise
+        FloatingPointError.  The precision options the model had (``strict_blocks`` included) are kept; on an exception the previous
+        setting is restored.  Returns and stores ``self.calibration``."""
         lib, h = _lib.load(), self._handle
         if not self._loaded and self._host_sd is not None:
             self.to("cuda")
@@ -272,6 +290,7 @@ class KEEPModel:
         if not h.value or lib.keep_vit_depth(h) == 0 or self._options["precision"] != _lib.PREC_COMP:
             return None
         dev, depth = self._device, int(lib.keep_vit_depth(h))
+        population = float(CALIBRATION_POPULATION if population is None else population)
         if tiles is None:
             g = torch.Generator(device=dev).manual_seed(seed)
             tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
@@ -283,13 +302,20 @@ class KEEPModel:
                 text_features = self.encode_text({k: v.to(dev) for k, v in toks.items()})
             else:
                 g = torch.Generator().manual_seed(seed + 1)
-                text_features = torch.nn.functional.normalize(torch.randn(64, self.config.projection_dim, generator=g), dim=-1)
-        bank = text_features.to(dev, torch.float32).t().contiguous()
+                text_features = torch.randn(64, self.config.projection_dim, generator=g).to(dev)
+                _lib.check(h, lib.keep_op_l2norm(h, _ptr(text_features), 64, self.config.projection_dim, _stream(dev)), "l2norm")
+        bank = text_features.to(dev, torch.float32).contiguous()
+        n_probe = tiles.shape[0] * bank.shape[0]
+        z_pop, z_probe = expected_max_sigmas(population), expected_max_sigmas(n_probe)
+        rms_target, max_target = tolerance / z_pop, tolerance * min(1.0, z_probe / z_pop)
+        saved = {k: self._options.get(k) for k in ("precision", "strict_blocks", "comp_full_blocks", "comp_mlp_blocks")}
+        strict_blocks = int(saved["strict_blocks"] or 0)
         was, self.auto_calibrate = self.auto_calibrate, False
+        done = False
         try:
-            self.set_precision("strict")
-            ref = self.encode_image(tiles) @ bank
-            self.set_precision("comp", self._options.get("strict_blocks", 0))
+            self.set_precision("strict", strict_blocks)
+            ref = self.similarity(self.encode_image(tiles), bank)           # cosines on the engine's exact-fp32 similarity kernel
+            self.set_precision("comp", strict_blocks)
             if not bool(torch.isfinite(ref).all()):
                 self._raise_flags(2)
             tried, chosen = [], None
@@ -297,21 +323,32 @@ class KEEPModel:
             for full, mlp in rungs:
                 self.set_option("comp_full_blocks", full)
                 self.set_option("comp_mlp_blocks", mlp)
-                d = (self.encode_image(tiles) @ bank - ref).abs()
+                d = self.similarity(self.encode_image(tiles), bank).sub_(ref).abs_()
                 err, rms = float(d.max()), float(d.pow(2).mean().sqrt())
                 tried.append({"comp_full_blocks": full, "comp_mlp_blocks": mlp, "max_abs_dcos": float(f"{err:.3e}"), "rms_dcos": float(f"{rms:.3e}")})
-                if err <= target and rms * CALIBRATION_SIGMAS <= tolerance:      # (NaN compares False: falls through to the next rung)
+                if err <= max_target and rms <= rms_target:      # (NaN compares False: falls through to the next rung)
                     chosen = (full, mlp)
                     break
             if chosen is None:
-                self.set_precision("strict")
+                self.set_precision("strict", strict_blocks)
             self.check_errors(wait=True)
+            done = True
         finally:
             self.auto_calibrate = was
+            if not done:                 # an exception mid-ladder: put back exactly what the caller had
+                for k, v in saved.items():
+                    if v is None:
+                        self._options.pop(k, None)
+                    else:
+                        self._options[k] = v
+                if self._handle.value:
+                    for k, v in self._options.items():
+                        lib.keep_set_option(self._handle, k.encode(), float(v))
         self.calibration = {"precision": "comp" if chosen else "strict", "comp_full_blocks": chosen[0] if chosen else None,
-                            "comp_mlp_blocks": chosen[1] if chosen else None, "target_max_abs_dcos": target,
-                            "target_rms_dcos": float(f"{tolerance / CALIBRATION_SIGMAS:.3e}"),
-                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[1]} prompts vs the split-product arithmetic", "tried": tried}
+                            "comp_mlp_blocks": chosen[1] if chosen else None, "population": population,
+                            "expected_max_sigmas": round(z_pop, 3), "target_max_abs_dcos": float(f"{max_target:.3e}"),
+                            "target_rms_dcos": float(f"{rms_target:.3e}"), "strict_blocks": strict_blocks,
+                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts vs the split-product arithmetic", "tried": tried}
         return self.calibration
 
     def get_option(self, name: str) -> float:
@@ -376,7 +413,11 @@ class KEEPModel:
         _lib.check(self._handle, _lib.load().keep_encode_image(self._handle, _ptr(xd), _lib.PIX_U8_HWC, xd.shape[0], _ptr(out),
                                                                _stream(self._device)), "encode_image_uint8")
         self._queue_flag_check(_stream(self._device))
-        return out if src_dev == self._device else out.to(src_dev)
+        if src_dev == self._device:
+            return out
+        res = out.to(src_dev)                  # host inputs: the copy back synchronises anyway, so the check is free and immediate
+        self.check_errors(wait=True)
+        return res
 
     @torch.no_grad()
     def resize_crop_uint8(self, images_u8: torch.Tensor, size: int = 224) -> torch.Tensor:
@@ -482,7 +523,14 @@ class KEEPModel:
             ev.record(torch.cuda.current_stream(self._device))
             self._pending_token_checks.append((flag, ev))
         elif self.check_token_ids:
-            self._raise_flags(lib.keep_token_error(self._handle, st))
+            self._raise_flags(self._error_bits(st))
+
+    def _error_bits(self, st) -> int:
+        """keep_token_error: the sticky error bits (>= 0, cleared by the call) or a negative error code -- a HIP failure must not be read as bits."""
+        rc = int(_lib.load().keep_token_error(self._handle, st))
+        if rc < 0:
+            _lib.check(self._handle, rc, "token_error")
+        return rc
 
     @staticmethod
     def _raise_flags(bits: int, earlier: bool = False):
@@ -510,7 +558,7 @@ class KEEPModel:
             self._flag_pool.append(flag)
         if bits:
             # acknowledge (clears the sticky bits); copies still in flight were taken before the clear and would repeat the report
-            bits |= _lib.load().keep_token_error(self._handle, _stream(self._device))
+            bits |= self._error_bits(_stream(self._device))
             for flag, ev in pend:
                 ev.synchronize()
                 self._flag_pool.append(flag)
@@ -600,7 +648,11 @@ class KEEPModel:
             self._queue_flag_check(_stream(self._device))
         self.last_rechecked = int(n.value)
         out = (sim, lab) + ((feats,) if return_features else ())
-        return out if src_dev == self._device else tuple(t.to(src_dev) for t in out)
+        if src_dev == self._device:
+            return out
+        out = tuple(t.to(src_dev) for t in out)
+        self.check_errors(wait=True)
+        return out
 
     def _ready_device(self):
         self.check_errors(wait=False)

@@ -169,3 +169,55 @@ def synth_tiles_device(a: int, b: int, device, dtype=torch.bfloat16, seed: int =
 def towers_of(state_dict) -> tuple:
     """Which towers a state_dict carries -- for ``KEEPModel(towers=...)`` when a single tower is loaded on purpose."""
     return tuple(t for t, pre in (("image", "visual."), ("text", "text.")) if any(k.startswith(pre) for k in state_dict))
+
+
+SYNTH_WORDS = ("an h & e image of a histopathology slide showing tissue with features consistent . , chromophobe clear cell papillary renal "
+               "carcinoma normal kidney tumor benign parenchyma kind type variant region").split()
+
+
+def write_synthetic_release(directory: str, shape: KEEPShape = KEEPShape(), seed: int = 0, weights: str = "safetensors",
+                            drop_keys=()) -> str:
+    """A release directory in the on-disk format ``AutoModel.from_pretrained(model_path)`` / ``AutoTokenizer.from_pretrained(model_path)``
+    open (zeroshot_subtyping_WSI.py:44-46, keep_inference.py:79-87): ``config.json`` (``model_type: keep``, ``text_config``,
+    ``projection_dim``), ``model.safetensors`` or ``pytorch_model.bin`` with seeded weights in the key layout of SURVEY.md A.3, and an
+    uncased WordPiece ``vocab.txt`` + ``tokenizer_config.json`` (a small word list padded to the text tower's vocabulary size).
+    ``drop_keys``: state_dict keys left out on purpose (strict-loading tests).  Returns ``directory``."""
+    import json
+    import os
+    os.makedirs(directory, exist_ok=True)
+    sd = {k: v.contiguous() for k, v in synth_state_dict(shape, seed=seed).items() if k not in set(drop_keys)}
+    if weights == "safetensors":
+        from safetensors.torch import save_file
+        save_file(sd, os.path.join(directory, "model.safetensors"))
+    elif weights == "bin":
+        torch.save(sd, os.path.join(directory, "pytorch_model.bin"))
+    else:
+        raise ValueError("weights: 'safetensors' or 'bin'")
+    t = shape.text
+    with open(os.path.join(directory, "config.json"), "w") as f:
+        json.dump({"model_type": "keep", "projection_dim": shape.projection_dim, "vision_config": None,
+                   "text_config": {"vocab_size": t.vocab_size, "hidden_size": t.hidden_size, "num_hidden_layers": t.num_hidden_layers,
+                                   "num_attention_heads": t.num_attention_heads, "intermediate_size": t.intermediate_size,
+                                   "max_position_embeddings": t.max_position_embeddings, "type_vocab_size": t.type_vocab_size,
+                                   "layer_norm_eps": t.layer_norm_eps, "hidden_act": "gelu"}}, f)
+    alnum = "abcdefghijklmnopqrstuvwxyz0123456789"
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + sorted(set(SYNTH_WORDS)) + [f"##{c}" for c in alnum] + list(alnum)
+    vocab += [f"[unused{i}]" for i in range(t.vocab_size - len(vocab))]
+    with open(os.path.join(directory, "vocab.txt"), "w") as f:
+        f.write("\n".join(vocab) + "\n")
+    with open(os.path.join(directory, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "BertTokenizer", "do_lower_case": True, "model_max_length": t.max_position_embeddings}, f)
+    return directory
+
+
+def synthetic_rcc_prompts(prompt_sets: int = 48, seed: int = 3) -> Dict[str, dict]:
+    """A prompt file with the structure the WSI scripts read (``prompts[str(i)] = {'classnames': {label: str}, 'templates': str}``,
+    zeroshot_subtyping_WSI.py:31-36, utils.py:86-104), drawn from the words of the synthetic vocabulary."""
+    import random
+    names = {"CHRCC": ["chromophobe renal cell carcinoma", "renal carcinoma chromophobe type"],
+             "CCRCC": ["clear cell renal cell carcinoma", "renal carcinoma clear cell type"],
+             "PRCC": ["papillary renal cell carcinoma", "renal carcinoma papillary variant"],
+             "Normal": ["normal kidney tissue", "benign renal parenchyma"]}
+    templates = ["an H&E image of CLASSNAME.", "a histopathology slide showing CLASSNAME.", "tissue with features consistent with CLASSNAME."]
+    rnd = random.Random(seed)
+    return {str(i): {"classnames": {k: rnd.choice(v) for k, v in names.items()}, "templates": rnd.choice(templates)} for i in range(prompt_sets)}

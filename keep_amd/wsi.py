@@ -28,12 +28,22 @@ from .model import KEEPModel, _ptr, _stream, engine_for
 # ------------------------------------------------------------------------------------------------
 class TextEmbeddingCache:
     """The RCC prompt bank asks for 7128 ``encode_text`` calls but holds only 264 distinct strings
-    (SURVEY.md §3.2): embed each distinct string once, in batches."""
+    (SURVEY.md §3.2): embed each distinct string once, in batches.  A cache that belongs to an engine (``_cache_for``) refers to it
+    weakly, so that it never keeps the model -- and its GPU weights -- alive."""
 
-    def __init__(self, KEEP_model: Mapping, device, batch: int = 64, max_length: int = 256):
-        self.model, self.tokenizer = KEEP_model["model"], KEEP_model["tokenizer"]
+    def __init__(self, KEEP_model: Mapping, device, batch: int = 64, max_length: int = 256, weak: bool = False):
+        model = KEEP_model["model"]
+        self._model = weakref.ref(model) if weak else (lambda: model)
+        self.tokenizer = KEEP_model["tokenizer"]
         self.device, self.batch, self.max_length = device, batch, max_length
         self._cache: Dict[str, torch.Tensor] = {}
+
+    @property
+    def model(self):
+        m = self._model()
+        if m is None:
+            raise ReferenceError("the model this prompt cache was built for no longer exists")
+        return m
 
     def embed(self, texts: Sequence[str]) -> torch.Tensor:
         todo = [t for t in dict.fromkeys(texts) if t not in self._cache]
@@ -48,9 +58,9 @@ class TextEmbeddingCache:
         return torch.stack([self._cache[t] for t in texts])
 
 
-# one cache per (model, tokenizer, weights): the reference scripts call get_zeroshot_classifier once per prompt set with the same
-# KEEP_model dict (zeroshot_subtyping_WSI.py:59-62), so repeated strings are embedded once without any change to the call site
-_auto_caches: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# one cache per (model, tokenizer, weights, precision setting): the reference scripts call get_zeroshot_classifier once per prompt set with
+# the same KEEP_model dict (zeroshot_subtyping_WSI.py:59-62), so repeated strings are embedded once without any change to the call site.
+# The cache lives ON the model object (and refers back to it weakly): it goes away with the model, and nothing global pins a model.
 PROMPT_CACHE = True          # False: embed every string on every call, exactly as the reference does
 
 
@@ -58,17 +68,30 @@ def _cache_for(KEEP_model, device) -> TextEmbeddingCache:
     m, tok = KEEP_model["model"], KEEP_model["tokenizer"]
     if not PROMPT_CACHE or not isinstance(m, KEEPModel):
         return TextEmbeddingCache(KEEP_model, device)
-    key = (id(tok), getattr(m, "_weights_epoch", 0), str(device))
-    slot = _auto_caches.get(m)
+    # embeddings depend on the weights and on the precision setting of the text tower: set_precision / set_option after the first call
+    # must not return embeddings computed under the old setting
+    key = (id(tok), getattr(m, "_weights_epoch", 0), str(device), tuple(sorted((k, float(v)) for k, v in m._options.items())))
+    slot = getattr(m, "_prompt_cache", None)
     if slot is None or slot[0] != key:
-        slot = (key, TextEmbeddingCache(KEEP_model, device))
-        _auto_caches[m] = slot
+        slot = (key, TextEmbeddingCache(KEEP_model, device, weak=True))
+        m._prompt_cache = slot
     return slot[1]
+
+
+def _unit_rows(m: KEEPModel, x: torch.Tensor) -> torch.Tensor:
+    """Rows of a 2-D fp32 tensor divided by max(||row||, 1e-12) on the engine (``F.normalize(x, dim=-1)`` semantics; keep_op_l2norm) --
+    torch holds the storage, the arithmetic is the engine's row kernel."""
+    dev = x.device
+    r = x.detach().to(m._device, torch.float32).contiguous().clone()
+    if r.numel():
+        _lib.check(m._handle, _lib.load().keep_op_l2norm(m._handle, _ptr(r), r.shape[0], r.shape[1], _stream(m._device)), "l2norm")
+    return r if dev == m._device else r.to(dev)
 
 
 def zero_shot_classifier(KEEP_model, classnames, templates, device, cache: Optional[TextEmbeddingCache] = None):
     """utils.py:64-84.  Returns [feat_dim, num_classes]."""
     cache = cache or _cache_for(KEEP_model, device)
+    eng = _engine(KEEP_model["model"] if isinstance(KEEP_model["model"], KEEPModel) else None, device=device)
     weights = []
     with torch.no_grad():
         for classname in classnames:
@@ -78,8 +101,8 @@ def zero_shot_classifier(KEEP_model, classnames, templates, device, cache: Optio
                 texts = [templates.replace("CLASSNAME", classname)]
             # the reference keeps only row 0 of the batch (`encode_text(text_inputs)[0]`, utils.py:74)
             class_embeddings = cache.embed(texts)[0].unsqueeze(0)
-            class_embedding = torch.nn.functional.normalize(class_embeddings, dim=-1).mean(dim=0)
-            class_embedding = class_embedding / class_embedding.norm()
+            # F.normalize(class_embeddings, dim=-1).mean(dim=0) over ONE row, then / norm (utils.py:76-80): two passes of the row kernel
+            class_embedding = _unit_rows(eng, _unit_rows(eng, class_embeddings))[0]
             weights.append(class_embedding)
     return torch.stack(weights, dim=1).to(device)
 
@@ -113,9 +136,10 @@ def build_classifier_bank(KEEP_model, label_map, prompts, device, add_normal=Fal
     for e in entries:
         tpl = e["templates"][0] if isinstance(e["templates"], list) else e["templates"]     # row 0 only, as utils.py:74
         texts.extend(tpl.replace("CLASSNAME", e["classnames"][idx_to_class[c]]) for c in range(C_))
+    eng = _engine(KEEP_model["model"] if isinstance(KEEP_model["model"], KEEPModel) else None, device=device)
     emb = cache.embed(texts).to(device, torch.float32)                                      # [K*C, D]
-    emb = torch.nn.functional.normalize(emb, dim=-1)           # normalize(class_embeddings, dim=-1).mean(dim=0) over ONE row
-    emb = emb / emb.norm(dim=-1, keepdim=True)                 # class_embedding /= class_embedding.norm()
+    emb = _unit_rows(eng, emb)                                 # normalize(class_embeddings, dim=-1).mean(dim=0) over ONE row
+    emb = _unit_rows(eng, emb)                                 # class_embedding /= class_embedding.norm()
     bank = emb.reshape(len(entries), C_, -1).permute(0, 2, 1).contiguous()                  # [K, D, C]
     return list(bank.unbind(0))
 
@@ -181,10 +205,10 @@ def zero_shot_prompt_select(classifiers, tile_features, topn, device, model=None
     merge = torch.zeros_like(classifiers[0], dtype=torch.float32)
     for cls_index in index[0:topn]:
         merge += classifiers[int(cls_index)].to(merge.device, torch.float32)
-    return torch.nn.functional.normalize(merge, p=2, dim=0)
+    return _unit_rows(m, merge.t()).t().contiguous()            # F.normalize(merge, p=2, dim=0): the columns are the class vectors
 
 
-def random_prompt_ensemble(classifiers: Sequence[torch.Tensor], topn: int) -> torch.Tensor:
+def random_prompt_ensemble(classifiers: Sequence[torch.Tensor], topn: int, model=None) -> torch.Tensor:
     """The `prompt_screening = False` branch of the three scripts (zeroshot_subtyping_WSI.py:68-76): `topn` picks with
     `random.seed(c); random.randint(0, K-1)` for c = 0..topn-1 (so the picks are the same on every run), summed and
     column-normalised."""
@@ -193,7 +217,7 @@ def random_prompt_ensemble(classifiers: Sequence[torch.Tensor], topn: int) -> to
     for cter in range(topn):
         random.seed(cter)
         ensemble_cls += classifiers[random.randint(0, len(classifiers) - 1)]
-    return torch.nn.functional.normalize(ensemble_cls, p=2, dim=0)
+    return _unit_rows(_engine(model, ensemble_cls), ensemble_cls.t()).t().contiguous()
 
 
 def cood2str(cood):

@@ -66,3 +66,65 @@ def test_bench_distributed_leg_runs_on_nccl():
     line = json.loads(r.stdout.strip().splitlines()[-1])          # the JSON line is the last thing on stdout, after RCCL's banner
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert "RCCL" in line["config"]["exchange"]
+
+
+def _rccl_worker(rank, world, port, n_tiles, q):
+    """One rank of the real thing: its own GPU, backend nccl (= RCCL over xGMI), the engine's encode on its shard."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from keep_amd.distributed import StepExchange, assert_same_setting, encode_tiles_sharded, rccl_env, shard_bounds, timed_steps
+    rccl_env()
+    import torch.distributed as dist
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.synth import synth_state_dict, synth_tiles_device
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        shape = small_shape(2, 2)
+        m = KEEPModel(shape, towers=("image",))
+        m.load_state_dict(synth_state_dict(shape, seed=3, text=False), strict=True)
+        m.to(dev).eval()
+        setting = assert_same_setting([m.get_option("comp_full_blocks"), m.get_option("comp_mlp_blocks")], device=dev)
+        load = lambda a, b: synth_tiles_device(a, b, dev, torch.bfloat16, seed=77, unit=64)
+        got = encode_tiles_sharded(m.encode_image, n_tiles, load, batch=32)           # ragged shards, pipelined all-gathers
+        ref = torch.cat([m.encode_image(load(a, min(a + 32, n_tiles))) for a in range(0, n_tiles, 32)])
+        # a shard's batches start at the shard boundary and its last one is shorter than the single-process run's: the small-batch kernels
+        # sum in another order, so rows agree to fp32 rounding (same batches -> same bits: the step loop below, and the world-1 test above)
+        ok = bool((got - ref).abs().max() < 1e-5) and got.shape == ref.shape
+        # bench.py's N > 1 step loop: double-buffered exchange, fences, MAX over ranks
+        ex = StepExchange(32, shape.projection_dim, dev)
+        lo, _ = shard_bounds(n_tiles, rank, world)
+        mine = load(lo, lo + 32)
+        def step():
+            ex.submit(m.encode_image(mine))
+        el = timed_steps(step, 4, ex)
+        last = ex.gathered((ex.steps - 1) % 2)
+        for r in range(world):
+            rlo, _ = shard_bounds(n_tiles, r, world)
+            ok = ok and bool(torch.equal(last[r * 32:(r + 1) * 32], m.encode_image(load(rlo, rlo + 32))))
+        q.put((rank, ok, el > 0, len(setting)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_tiles", [150, 97])
+def test_two_ranks_over_rccl_match_the_single_process_result(n_tiles):
+    """Needs two MI355X in one node (skipped on the one-GPU test box): two processes, one per GPU, backend nccl.  The sharded encode with
+    ragged shards and asynchronous all-gathers returns, on every rank, exactly the rows a single process computes; the bench's step loop
+    (StepExchange / timed_steps) delivers every rank's batch to every rank."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs in the node (RCCL between processes)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, n_tiles, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert [r[0] for r in res] == [0, 1] and all(r[1] and r[2] and r[3] == 2 for r in res), res

@@ -757,14 +757,37 @@ def test_fp16_range_of_the_qkv_and_hidden_stores(small, text_bank):
     with pytest.raises(FloatingPointError):
         m.auto_calibrate = True
         m.calibrate()                                                   # calibration refuses such weights too
-    # the operand planes themselves: a GEMM weight below fp16's normal range (this is what dividing fc2 by 8000 instead of the
-    # LayerScale would do: 1.2e-3 cosine error, invisible to calibrate() because the split-product mode loses the same bits) or
-    # beyond its maximum is refused at load
-    for key, factor, what in (("visual.blocks.0.mlp.fc2.weight", 1.0 / 8000.0, "subnormal"), ("visual.blocks.1.attn.qkv.weight", 1e7, "65504")):
-        bad = dict(small)
-        bad[key] = small[key] * factor
-        with pytest.raises(ValueError, match=what):
-            make_model(bad, "comp")
+    # the operand planes themselves: a GEMM weight beyond fp16's maximum is refused at load ...
+    bad = dict(small)
+    bad["visual.blocks.1.attn.qkv.weight"] = small["visual.blocks.1.attn.qkv.weight"] * 1e7
+    with pytest.raises(ValueError, match="65504"):
+        make_model(bad, "comp")
+
+
+def test_weights_below_the_fp16_window_load(small, text_bank):
+    """A projection whose magnitude lives in its LayerScale (fc2 / 8000, ls2 x 8000: the same function) would put fc2's entries into fp16
+    subnormals -- 1.2e-3 in cosine if stored as they are, and invisible to calibrate(), whose split-product yardstick loses the same bits.
+    proj / fc2 planes are therefore pre-scaled by a power of two with LayerScale / bias adjusted (exact), and the load says so; any other
+    tiny weight (a dead layer) loads with a warning, as torch's load_state_dict would (keep_inference.py:83).  Nothing is refused."""
+    x = synth_tiles(6, seed=12)
+    folded = dict(small)
+    folded["visual.blocks.0.mlp.fc2.weight"] = small["visual.blocks.0.mlp.fc2.weight"] / 8192.0
+    folded["visual.blocks.0.mlp.fc2.bias"] = small["visual.blocks.0.mlp.fc2.bias"] / 8192.0
+    folded["visual.blocks.0.ls2.gamma"] = small["visual.blocks.0.ls2.gamma"] * 8192.0
+    with torch.no_grad():
+        want = O.encode_image(small, x)                       # powers of two: the folded weights are the same function, bit for bit in fp32
+    for precision in ("strict", "comp"):
+        with pytest.warns(RuntimeWarning, match="fc2.weight.*stored as 2\\^"):
+            m = make_model(folded, precision)
+        got = m.encode_image(x.cuda()).cpu()
+        d = (got @ text_bank.t() - want @ text_bank.t()).abs().max().item()
+        print(f"[fc2 / 8192 {precision}] max|dcos| = {d:.3e}")
+        assert d < tol(precision, 3e-6)
+    dead = dict(small)
+    dead["visual.blocks.1.attn.qkv.weight"] = small["visual.blocks.1.attn.qkv.weight"] * 1e-3
+    with pytest.warns(RuntimeWarning, match="qkv.weight.*subnormals"):
+        m = make_model(dead, "comp")
+    assert bool(torch.isfinite(m.encode_image(x.cuda())).all())
 
 
 def test_text_graph_replay_covers_a_64_prompt_bank_chunk(small):
