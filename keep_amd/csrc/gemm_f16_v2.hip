@@ -32,7 +32,6 @@
 #ifndef KEEP_W_AUX
 #define KEEP_W_AUX 0
 #endif
-
 namespace keepk {
 
 constexpr int V2_BM = 256, V2_BK = 32;
@@ -109,7 +108,10 @@ void gemm_f16_v2_kernel(GemmParams p) {
     const int nwg = (EPI == EPI_PARTIAL || PERS) ? ntn * mtn : (int)gridDim.x;
     const int zsplit = (EPI == EPI_PARTIAL) ? (int)blockIdx.x / nwg : 0;
     const int bidx = (EPI == EPI_PARTIAL) ? (int)blockIdx.x - zsplit * nwg : (int)blockIdx.x;
-    constexpr int BW = 2048 / BN;             // band of n-tiles that share an A panel on one XCD (8 tiles of 256: measured 2.5 % better than 4 on fc1)
+#ifndef KEEP_BAND_COLS
+#define KEEP_BAND_COLS 2048
+#endif
+    constexpr int BW = KEEP_BAND_COLS / BN;   // band of n-tiles that share an A panel on one XCD (8 tiles of 256: measured 2.5 % better than 4 on fc1)
     auto tile_of = [&](int b, int& tm_, int& tn_) {
         const int xcd = b & 7, slot = b >> 3;
         const int q = nwg >> 3, r = nwg & 7;
@@ -661,7 +663,8 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x[e] += bias4[0][e];
-                    x[e] = (EPI == EPI_RESID_LS) ? res2[j & 1][it][e] + ls4[0][e] * x[e] : res2[j & 1][it][e] + x[e];
+                    // LayerScale product rounded on its own, then added (torch's `x + gamma * y`, and what the atomic form computes): no fused multiply-add here
+                    x[e] = (EPI == EPI_RESID_LS) ? res2[j & 1][it][e] + __fmul_rn(ls4[0][e], x[e]) : res2[j & 1][it][e] + x[e];
                 }
                 if (mbase + r < p.M) {
                     float* dst = (EPI == EPI_PARTIAL) ? p.splitk_ws : (EPI == EPI_RESID_F32) ? p.out_f32 : p.resid;

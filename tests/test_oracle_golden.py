@@ -125,7 +125,6 @@ def test_weighted_f1_is_sklearns():
 def test_unscreened_ensemble_is_deterministic(golden_dir):
     """`prompt_screening = False` branch (zeroshot_subtyping_WSI.py:68-76): the seeded picks are fixed numbers."""
     import random
-    from keep_amd.wsi import random_prompt_ensemble
     g = np.load(os.path.join(golden_dir, "wsi_logic.npz"))
     cls4 = [torch.from_numpy(c) for c in g["cls4"]]
     picks = []
@@ -134,7 +133,7 @@ def test_unscreened_ensemble_is_deterministic(golden_dir):
         picks.append(random.randint(0, len(cls4) - 1))
     want = torch.nn.functional.normalize(sum(cls4[i] for i in picks), p=2, dim=0)
     assert torch.allclose(O.random_prompt_ensemble(cls4, 10), want, atol=1e-7)
-    assert torch.equal(random_prompt_ensemble(cls4, 10), O.random_prompt_ensemble(cls4, 10))
+    # (the product's random_prompt_ensemble normalises on the engine: tests/test_wsi_gpu.py::test_unscreened_ensemble_on_the_engine)
     assert (want.norm(dim=0) - 1).abs().max() < 1e-6
 
 

@@ -697,7 +697,7 @@ def test_calibrate_walks_the_ladder_and_reports(small):
     assert m.calibration["precision"] == "comp" and m.calibration["comp_full_blocks"] <= 2       # depth-2 model: rungs clamp to its depth
     assert m.get_option("comp_full_blocks") == m.calibration["comp_full_blocks"] and m.get_option("comp_mlp_blocks") == m.calibration["comp_mlp_blocks"]
     # an unreachable target walks every rung and ends in the split-product mode
-    cal = m.calibrate(n_tiles=64, target=1e-9)
+    cal = m.calibrate(n_tiles=64, tolerance=1e-9)
     assert cal["precision"] == "strict" and len(cal["tried"]) >= 2 and m.get_option("precision") == 1
     errs = [t["max_abs_dcos"] for t in cal["tried"]]
     assert errs[-1] <= errs[0] * 1.2                       # more compensated blocks: not worse
@@ -707,8 +707,17 @@ def test_calibrate_walks_the_ladder_and_reports(small):
     assert (m.encode_image(x).cpu() - ref).abs().max() < 5e-6
     # a generous target keeps the first rung; explicit probe tiles and prompts are accepted
     m.set_precision("comp")
-    cal = m.calibrate(tiles=synth_tiles(40, seed=9).to(torch.bfloat16), text_features=torch.nn.functional.normalize(torch.randn(7, 768), dim=-1), target=1e-3, tolerance=1e-2)
+    cal = m.calibrate(tiles=synth_tiles(40, seed=9).to(torch.bfloat16), text_features=torch.nn.functional.normalize(torch.randn(7, 768), dim=-1), tolerance=1e-2)
     assert cal["precision"] == "comp" and len(cal["tried"]) == 1 and "40 tiles x 7 prompts" in cal["probe"]
+    # the rule is population-aware: a larger population (more tiles x distinct prompts to compare) asks for a smaller rms, never a larger one
+    small_pop, large_pop = m.calibrate(population=1e4), m.calibrate(population=1e9)
+    assert small_pop["target_rms_dcos"] > large_pop["target_rms_dcos"] and small_pop["expected_max_sigmas"] < large_pop["expected_max_sigmas"]
+    rung = lambda c: (c["comp_full_blocks"] if c["precision"] == "comp" else 99, c["comp_mlp_blocks"] if c["precision"] == "comp" else 99)
+    assert rung(small_pop) <= rung(large_pop)
+    # strict_blocks set by the caller survives a calibration (it used to be reset to 0)
+    m.set_precision("comp", strict_blocks=1)
+    m.calibrate()
+    assert m.get_option("strict_blocks") == 1 and m.calibration["strict_blocks"] == 1
     fp = make_model(small, "fp16")
     assert fp.calibration is None and fp.calibrate() is None            # only the compensated mode has something to choose
 

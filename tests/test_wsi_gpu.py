@@ -177,3 +177,14 @@ def test_refine_seg_dicts_have_the_reference_form(g, model):
     assert np.abs(np.array(list(seg.values())) - g["seg_probs"]).max() < 1e-6
     with pytest.raises(NotImplementedError):
         segment_utils.zero_shot_segment(ens2, feats, g["coords224"], "mask.tif")
+
+
+def test_unscreened_ensemble_on_the_engine(g):
+    """Row a13, the `prompt_screening = False` branch (zeroshot_subtyping_WSI.py:68-76): same seeded picks as the oracle's restatement, the
+    column normalisation on the engine's row kernel; classifiers on the host come back on the host."""
+    cls4 = [torch.from_numpy(c) for c in g["cls4"]]
+    want = O.random_prompt_ensemble(cls4, 10)
+    got = wsi.random_prompt_ensemble(cls4, 10)
+    assert got.device.type == "cpu" and got.shape == want.shape and (got - want).abs().max() < 2e-7
+    got = wsi.random_prompt_ensemble([c.cuda() for c in cls4], 10)
+    assert got.device.type == "cuda" and (got.cpu() - want).abs().max() < 2e-7
