@@ -10,11 +10,13 @@ all-gather of the [256,768] embeddings when N > 1: the slide-level pooling excha
 Rank 0 prints ONE JSON line.  `value` is measured over exactly --steps steps, in the DEFAULT precision mode
 ('comp': the fastest mode whose cosines stay within the 1e-4 reference tolerance); on top of that contract the line carries
   sustained   the same step repeated for >= 10 s (the part runs at its power cap; a sub-second burst is not a sustained rate)
-  roofline    the dominant GEMM (vit.fc1), HIP-event timed inside the timed region, + the same kernel on one stream
+  roofline    the time-dominant kernel (the persistent fp32-residual GEMM: vit.proj + vit.fc2), HIP-event timed on one stream with nothing
+              else on the GPU (a KERNEL figure); the same launches inside the two-lane timed region under a separate key; every other kernel
   parity      BASELINE config 3 (4096 tiles x 64 prompts through both towers, similarity + argmax) against the committed
               fp32-oracle fixture tests/golden/c3_dual_tower.npz: 262 144 cosines, match-rate, argmax agreement
-  configs     c3 (dual tower) and c5 (100 000-tile x 2-class fp16 probability map) throughput figures
-  cpu_baseline  the oracle's encode_image on the host cores (bounded sample)
+  configs     c3 (dual tower), c4 (100 000-tile slide: every cosine of the benched setting against the split-product mode, screening scores,
+              slide label, tumour ratio) and c5 (100 000-tile x 2-class fp16 probability map)
+  cpu_baseline  the oracle's encode_image and encode_text on the host cores (bounded samples)
 """
 from __future__ import annotations
 
@@ -40,7 +42,11 @@ from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles    # noq
 
 PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense
 PEAK_HBM_GBS = 8000.0
-DOMINANT_TAG = "vit.fc1"     # gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,*> (persistent walk in the plain blocks, fp4 phase in the compensated ones): [B*197,1024] x [1024,4096], 32 % of the FLOPs
+# The kernel that takes the largest share of a step: gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,false,true> -- the persistent 256x256 GEMM with the
+# LayerScale + fp32 residual read-modify-write epilogue, launched for proj ([B*197,1024] x [1024,1024]) and fc2 ([B*197,4096] x [4096,1024]) of every
+# block that runs single fp16 passes (26-27 % of the step; profiles/r03_per_kernel_table.md).  The engine times those launches under these two tags.
+DOMINANT_TAGS = ("vit.proj", "vit.fc2")
+DOMINANT_KERNEL = "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,false,true> (persistent; vit.proj + vit.fc2 launches of the plain blocks)"
 BERT_FLOPS_PER_PROMPT_256 = 45_903_642_624
 DTYPE_NAME = {"fp16": "fp16", "comp": "fp16+mxfp4", "strict": "fp16x3"}
 
@@ -75,7 +81,9 @@ def cpu_model_name() -> str:
 
 
 def cpu_baseline(sd, tiles: int = 8, iters: int = 40, min_seconds: float = 10.0):
-    """The oracle (fp32 torch-CPU restatement of the reference's encode_image) on the host cores."""
+    """The oracle (fp32 torch-CPU restatement of the reference's encode_image / encode_text) on the host cores: tiles/s and, as SURVEY.md 8(d)
+    asks, prompts/s on 8 prompts x 256 tokens.  Thread policy: torch intra-op threads = the cores this process may use (affinity mask capped by
+    the cgroup quota), at most 64; one process."""
     from oracle import keep_oracle as O
     torch.set_num_threads(min(usable_cpus(), 64))
     x = synth_tiles(tiles, seed=0)
@@ -89,10 +97,23 @@ def cpu_baseline(sd, tiles: int = 8, iters: int = 40, min_seconds: float = 10.0)
             if time.perf_counter() - t0 > min_seconds:              # bounded sample: ~10 s of CPU work
                 break
         dt = time.perf_counter() - t0
+        toks = synth_prompts(8, 256, seed=1)
+        O.encode_text(sd, {k: v[:1] for k, v in toks.items()})      # warm-up
+        t1 = time.perf_counter()
+        pdone = 0
+        for _ in range(12):
+            O.encode_text(sd, toks)
+            pdone += 1
+            if time.perf_counter() - t1 > 4.0:                      # ~4 s more
+                break
+        pdt = time.perf_counter() - t1
     iters = done
     return {"value": round(tiles * iters / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} x {tiles} synthetic 224x224 tiles, fp32 torch-CPU restatement (oracle/keep_oracle.py) "
-                      f"of KEEPModel.encode_image, same synthetic weights; CPU: {cpu_model_name()}"}
+            "prompts_per_s": round(8 * pdone / pdt, 2),
+            "thread_policy": "one process, torch intra-op threads = min(cores granted by affinity mask and cgroup quota, 64)",
+            "sample": f"{iters} x {tiles} synthetic 224x224 tiles through encode_image and {pdone} x 8 prompts x 256 tokens (padded length, as the "
+                      "reference computes it) through encode_text, fp32 torch-CPU restatement (oracle/keep_oracle.py) of KEEPModel, same "
+                      f"synthetic weights; CPU: {cpu_model_name()}"}
 
 
 def lib_sha16() -> str:
@@ -187,6 +208,109 @@ def config3(model, dev):
     return cfg, parity
 
 
+def rcc_shaped_bank(txt, K=1782, C=4, seed=11):
+    """K prompt sets x C classes drawn from few distinct strings, as the RCC prompt file: class c draws from its own
+    share of the distinct text embeddings; a classifier column is a unit text embedding."""
+    g = torch.Generator().manual_seed(seed)
+    per_class = txt.shape[0] // C
+    picks = torch.stack([torch.randint(0, per_class, (K,), generator=g) + c * per_class for c in range(C)], 1)      # [K, C]
+    return [txt[p.to(txt.device)].t().contiguous() for p in picks]
+
+
+def diff_stats(d):
+    from keep_amd.model import expected_max_sigmas
+    mx, rms = float(d.abs().max()), float(d.double().pow(2).mean().sqrt())
+    return {"max_abs": float(f"{mx:.3e}"), "rms": float(f"{rms:.3e}"), "max_over_rms": round(mx / max(rms, 1e-30), 2), "n": int(d.numel()),
+            "gaussian_expectation_of_max_over_rms": round(expected_max_sigmas(d.numel()), 2), "over_1e-4": int((d.abs() > 1e-4).sum())}
+
+
+def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, topn: int = 50, settings=None):
+    """BASELINE config 4 at its stated size on one GPU: a 100 000-tile synthetic slide (tiles generated on the device, 256 per batch) encoded in the
+    model's current 'comp' setting and in 'strict' (split products: pinned to 6.4e-7 of the fp32 oracle on config 3), then the reference's subtyping /
+    detection flow on both feature sets.  Reports every cosine difference against a 64-prompt bank (N x 64) and against the `distinct` prompt strings a
+    K x 4 classifier bank of the RCC shape is built from (N x 264 distinct cosines = everything the N x 7128 screening logits can contain), the
+    screening scores, the selected ensemble, the slide label and the tumour ratio.  `settings`: extra (comp_full_blocks, comp_mlp_blocks) pairs to
+    measure the same way (tools/c4_parity.py); the model's own setting is always measured and restored."""
+    from keep_amd import wsi
+    from keep_amd.synth import synth_tiles_device
+
+    def encode_all():
+        out = torch.empty(n, 768, device=dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for a in range(0, n, 256):
+            b = min(a + 256, n)
+            out[a:b] = model.encode_image(synth_tiles_device(a, b, dev, torch.bfloat16, seed=1000))
+        torch.cuda.synchronize(dev)
+        return out, time.perf_counter() - t0
+
+    own = (int(model.get_option("comp_full_blocks")), int(model.get_option("comp_mlp_blocks")))
+    prec_was, sb_was = model._options["precision"], int(model._options.get("strict_blocks", 0))
+    toks64, toksD = synth_prompts(64, 256, seed=1), synth_prompts(distinct, 256, seed=5)
+    out = {"workload": f"config 4 on one GPU: {n} synthetic tiles (device-generated, bf16), 64-prompt bank, {distinct} distinct prompts -> K = {K} x C = 4 "
+                       f"classifier bank ({K * 4} columns), prompt screening (topn {topn}), subtyping on a 256-px grid, detection (C = 2)",
+           "reference": "the engine's 'strict' mode on the same tiles (split products; 6.4e-7 of the fp32 oracle on config 3: tests/golden/c3_dual_tower.npz)"}
+    try:
+        model.set_precision("strict", sb_was)
+        txt64 = model.encode_text({k: v.to(dev) for k, v in toks64.items()})
+        txtD = torch.cat([model.encode_text({k: v[i:i + 64].to(dev) for k, v in toksD.items()}) for i in range(0, distinct, 64)])
+        f_s, t_s = encode_all()
+        out["strict_tiles_per_s"] = round(n / t_s, 1)
+        sim64_s, simD_s = model.similarity(f_s, txt64), model.similarity(f_s, txtD)
+        bank4 = rcc_shaped_bank(txtD, K)
+        bank2 = [c[:, :2].contiguous() for c in bank4]
+        side = int(n ** 0.5) + 1
+        idx = torch.arange(n)
+        coords = torch.stack([(idx % side) * 256, (idx // side) * 256], 1).numpy()
+        sc_s = wsi.prompt_scores(f_s, bank4, model=model)
+        ens4_s = wsi.zero_shot_prompt_select(bank4, f_s, topn, dev, model=model)
+        ens2_s = wsi.zero_shot_prompt_select(bank2, f_s, topn, dev, model=model)
+        label_s = int(wsi.zero_shot_subtyping(ens4_s, f_s, coords, 256, True, model=model))
+        p2_s = model.similarity(f_s, ens2_s.t().contiguous(), scale=10.0, mode="softmax")
+        ratio_s = wsi.zero_shot_detection(ens2_s, f_s, coords, 256, False, model=model)
+        todo = [own] + [tuple(st) for st in (settings or []) if tuple(st) != own]
+        for full, mlp in todo:
+            model.set_precision("comp", sb_was)
+            model.set_option("comp_full_blocks", full)
+            model.set_option("comp_mlp_blocks", mlp)
+            f, t = encode_all()
+            e = (f - f_s).norm(dim=1)
+            r = {"comp_full_blocks": full, "comp_mlp_blocks": mlp, "tiles_per_s_incl_tile_generation": round(n / t, 1),
+                 "feature_error_norm": {"max": float(f"{float(e.max()):.3e}"), "rms": float(f"{float(e.pow(2).mean().sqrt()):.3e}")},
+                 "cos_vs_64_prompts": diff_stats(model.similarity(f, txt64) - sim64_s),
+                 f"cos_vs_{distinct}_distinct_prompts": diff_stats(model.similarity(f, txtD) - simD_s)}
+            sc = wsi.prompt_scores(f, bank4, model=model)
+            ens4 = wsi.zero_shot_prompt_select(bank4, f, topn, dev, model=model)
+            ens2 = wsi.zero_shot_prompt_select(bank2, f, topn, dev, model=model)
+            r["screening_scores"] = {"max_abs_diff": float(f"{float((sc - sc_s).abs().max()):.3e}"),
+                                     "same_top_n": bool(set(torch.topk(sc, topn).indices.tolist()) == set(torch.topk(sc_s, topn).indices.tolist()))}
+            r["ensemble_classifier_max_abs_diff"] = float(f"{float((ens4 - ens4_s).abs().max()):.3e}")
+            r["slide_label"] = [int(wsi.zero_shot_subtyping(ens4, f, coords, 256, True, model=model)), label_s]
+            r["slide_label_equal"] = r["slide_label"][0] == label_s
+            ratio = wsi.zero_shot_detection(ens2, f, coords, 256, False, model=model)
+            p2 = model.similarity(f, ens2_s.t().contiguous(), scale=10.0, mode="softmax")           # same classifier on both sides: the tile-level comparison
+            flipped = (p2[:, 1] > 0.5) != (p2_s[:, 1] > 0.5)
+            cs = model.similarity(f_s, ens2_s.t().contiguous())
+            cosm = (cs[:, 1] - cs[:, 0]).abs()
+            r["tumour_ratio"] = [ratio, ratio_s]
+            r["tumour_tile_calls"] = {"tiles_whose_call_differs": int(flipped.sum()),
+                                      "largest_strict_cos_margin_of_such_a_tile": float(f"{(float(cosm[flipped].max()) if bool(flipped.any()) else 0.0):.3e}"),
+                                      "note": "a tile's tumour call is argmax over two cosines: it can only differ where the two are closer than twice the cosine tolerance "
+                                              "(KEEPModel.classify re-encodes such tiles when the labels themselves are the product)"}
+            r["prob_map_max_abs_diff"] = float(f"{float((p2 - p2_s).abs().max()):.3e}")
+            key = "headline_setting" if (full, mlp) == own else f"setting_{full}_{mlp}"
+            out[key] = r
+        h = out["headline_setting"]
+        out["max_abs_dcos_vs_strict"] = h["cos_vs_64_prompts"]["max_abs"]
+        out[f"max_abs_dcos_vs_strict_{distinct}_distinct_prompts"] = h[f"cos_vs_{distinct}_distinct_prompts"]["max_abs"]
+        out["within_1e-4"] = bool(h["cos_vs_64_prompts"]["over_1e-4"] == 0 and h[f"cos_vs_{distinct}_distinct_prompts"]["over_1e-4"] == 0)
+    finally:
+        model.set_precision({0: "fp16", 1: "strict", 2: "comp"}[int(prec_was)], sb_was)
+        model.set_option("comp_full_blocks", own[0])
+        model.set_option("comp_mlp_blocks", own[1])
+    return out
+
+
 def config5(model, dev, n: int = 100_000):
     """BASELINE config 5: per-tile dense similarity map, fp16: softmax(10 * cos) over 2 classes for a 100 000-tile slide."""
     from oracle import keep_oracle as O
@@ -217,7 +341,9 @@ def main():
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the config-3 parity / config-3 / config-5 legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config-3 parity / config-3 / config-4 / config-5 legs")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 100 000-tile config-4 leg (about a minute)")
+    ap.add_argument("--c4-tiles", type=int, default=100_000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -267,26 +393,48 @@ def main():
             exchange.submit(f)
         return f
 
-    def timed(n_steps):
+    def timed(n_steps, own=None):
         if use_dist:
-            return timed_steps(step, n_steps, exchange)          # fence (collectives + barrier + device sync), n steps, fence, MAX over ranks
+            return timed_steps(step, n_steps, exchange, own)     # fence (collectives + barrier + device sync), n steps, fence, MAX over ranks
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
         torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0
+        el = time.perf_counter() - t0
+        if own is not None:
+            own.append(el)
+        return el
 
+    if use_dist:
+        # every rank calibrates on its own at load: a scaling figure must not mix settings
+        from keep_amd.distributed import assert_same_setting
+        assert_same_setting([model.get_option("precision"), model.get_option("comp_full_blocks"), model.get_option("comp_mlp_blocks")],
+                            "precision setting (precision, comp_full_blocks, comp_mlp_blocks)", device=dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
     log("warm-up done")
-    model.profile_enable(DOMINANT_TAG)
+    model.profile_enable(",".join(DOMINANT_TAGS))
     model.profile_reset()
-    elapsed = timed(args.steps)                                      # THE timed region of the contract: exactly --steps steps
-    dom_ms, dom_n, dom_flops = model.profile_read(DOMINANT_TAG)
+    own_elapsed = []
+    elapsed = timed(args.steps, own_elapsed)                          # THE timed region of the contract: exactly --steps steps
+    in_region = {t: model.profile_read(t) for t in DOMINANT_TAGS}
     model.profile_disable()
     log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+    per_rank = exchange_cost = None
+    if use_dist:
+        t = torch.tensor([own_elapsed[0]], device=dev, dtype=torch.float64)
+        rows = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(rows, t)
+        per_rank = [round(B * args.steps / float(r.item()), 1) for r in rows]
+        # what the exchange costs on the critical path: the same steps without it, same fences
+        def bare():
+            model.encode_image(tiles)
+        el0 = timed_steps(bare, args.steps, exchange)
+        exchange_cost = {"ms_per_step_with_exchange": round(elapsed / args.steps * 1e3, 3), "ms_per_step_encode_only": round(el0 / args.steps * 1e3, 3),
+                         "exposed_ms_per_step": round((elapsed - el0) / args.steps * 1e3, 3),
+                         "bytes_gathered_per_step": world * B * shape.projection_dim * 4}
 
     # effective shader clock under this load: a one-wave probe (shader cycles against the 100 MHz reference counter) on a side stream, right after
     # the timed region (the queue is still full of encodes: the probe lands between them) and again during the sustained region
@@ -320,73 +468,84 @@ def main():
              "how": "keep_clock_probe: one wavefront counting shader cycles against the 100 MHz reference for 300 us on a side stream while encode steps run",
              "peak_quoted_at_MHz": 2400} if mhz else None
 
-    # untimed pass on ONE internal stream: clean per-kernel times (lanes do not overlap) for the breakdown and for the
-    # dominant kernel in isolation
-    breakdown, iso = None, None
+    # untimed pass on ONE internal stream: per-kernel times with nothing else on the GPU (lanes do not overlap): the breakdown, and the KERNEL figure
+    # of the roofline block (HIP events around every launch, on the stream it is launched on)
+    breakdown, single = None, {}
     if not args.no_breakdown and rank == 0:
         streams_was = model._options.get("streams", 2)
         model.set_option("streams", 1)
         model.profile_enable(None)
         model.profile_reset()
-        for _ in range(2):
+        n_pass = 3
+        for _ in range(n_pass):
             model.encode_image(tiles)
         torch.cuda.synchronize(dev)
         breakdown = {}
         for tag in PROFILE_TAGS:
             ms, n, fl = model.profile_read(tag)
             if n:
-                breakdown[tag] = round(ms / 2, 3)
-            if tag == DOMINANT_TAG and n:
-                iso = {"achieved": round(fl / (ms * 1e-3) / 1e12, 1), "avg_launch_ms": round(ms / n, 4), "launches": n}
+                breakdown[tag] = round(ms / n_pass, 3)
+                single[tag] = (ms, n, fl)
         model.profile_disable()
         model.set_option("streams", streams_was)
 
-    c3 = c5 = parity = None
+    c3 = c4 = c5 = parity = None
     if want_configs:
         log("config 3 (4096 tiles x 64 prompts, parity vs the oracle fixture) ...")
         c3, parity = config3(model, dev)
         c5 = config5(model, dev)
         if parity is not None and not parity["labels_bit_exact"]:
             log(f"WARNING: {parity['argmax_mismatches']} config-3 labels differ from the fp32 oracle's -- the north star asks for bit-exact labels")
+        if not args.no_c4 and args.precision == "comp":
+            log(f"config 4 ({args.c4_tiles} tiles: the benched setting against the split-product mode) ...")
+            c4 = config4(model, dev, n=args.c4_tiles)
+            if not c4["within_1e-4"]:
+                log("WARNING: config 4 holds cosines that differ from the split-product mode by more than 1e-4 in the benched setting")
         log("configs done")
 
     line = None
     if rank == 0:
         tiles_per_s = world * B * args.steps / elapsed
-        avg_ms = dom_ms / max(dom_n, 1)
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0     # algorithmic FLOPs (2*M*N*K per launch) / summed launch time
-        # HBM traffic of the dominant kernel: PMC counters need rocprofv3 around the process (separate FETCH_SIZE / WRITE_SIZE passes, guide's gfx950
-        # correction), so it is read from the committed summary of `tools/refresh_profiles.sh` and labelled with the library build it was taken on
+        frac_e2e = tiles_per_s / world * vit_flops_per_tile() / (PEAK_F16_TFLOPS * 1e12)
+
+        def rate(ms, n, fl):
+            return {"achieved": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0, "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4) if ms > 0 else 0.0,
+                    "avg_launch_ms": round(ms / max(n, 1), 4), "launches": int(n), "flops_per_launch": round(fl / max(n, 1), 1)}
+
+        # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3 around the process (separate FETCH_SIZE / WRITE_SIZE passes, the guide's
+        # gfx950 correction), so it is read from the committed summary of tools/refresh_profiles.sh and labelled with the library build it was taken on
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03"):
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    tj = json.load(open(tpath))
-                    traffic = tj.get(DOMINANT_TAG, {}).get("bytes_per_launch")
+                    tj = json.load(open(tpath)).get("vit.proj+fc2", {})
+                    traffic = tj.get("bytes_per_launch")
                     sha_path = os.path.join(ROOT, "profiles", f"{rnd}_lib_sha16.txt")
                     sha = open(sha_path).read().strip() if os.path.exists(sha_path) else "unrecorded"
-                    traffic_src = (f"profiles/{rnd}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of the plain persistent fc1 kernel, "
-                                   f"measured on library build {sha}; this run's library is {lib_sha16()}")
+                    traffic_src = (f"profiles/{rnd}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this kernel in the two-lane run "
+                                   f"(128-tile launches, proj and fc2 mixed; algorithmic: {tj.get('algorithmic_bytes_per_launch')}), measured on library build {sha}; "
+                                   f"this run's library is {lib_sha16()}")
                     break
                 except (OSError, ValueError):
                     traffic = None
-        frac_e2e = tiles_per_s / world * vit_flops_per_tile() / (PEAK_F16_TFLOPS * 1e12)
-        roofline = {"bound": "mfma", "kernel": "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_GELU_F16,{persistent plain | +mxfp4 phase}> (vit.fc1)",
-                    "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "timing": "two_lane_in_region",
-                    "avg_launch_ms": round(avg_ms, 4), "launches": dom_n,
-                    "flops_per_launch": round(dom_flops / max(dom_n, 1), 1),
+        dom = [single.get(t, (0.0, 0, 0.0)) for t in DOMINANT_TAGS]
+        dom_ms, dom_n, dom_fl = (sum(d[i] for d in dom) for i in range(3))
+        roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", **rate(dom_ms, dom_n, dom_fl),
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "timing": "single_stream_pass: HIP events around every launch of this kernel, on the stream it is launched on, 3 encode calls of 256 tiles with one "
+                              "internal stream (nothing else on the GPU): a kernel figure, comparable with profiles/r04_rocprofv3_kernel_stats_single_stream.csv",
+                    "share_of_single_stream_step": round(dom_ms / max(sum(v[0] for v in single.values()), 1e-9), 4) if single else None,
+                    "by_operator": {t: rate(*single[t]) for t in DOMINANT_TAGS if t in single},
+                    "in_timed_region_two_lane": {**rate(*(sum(in_region[t][i] for t in DOMINANT_TAGS) for i in range(3))),
+                                                 "note": "the same kernel's launches INSIDE the timed region, where two 128-tile lanes share the GPU: a launch's "
+                                                         "duration includes the time it spends beside the other lane's kernels -- not a kernel figure"},
+                    "other_kernels_single_stream": {t: rate(*single[t]) for t in ("vit.qkv", "vit.fc1", "vit.fc1.x", "vit.fc2.x", "vit.qkv.x", "vit.proj.x", "vit.patch")
+                                                    if t in single},
                     "frac_end_to_end": round(frac_e2e, 4),
-                    "note": "achieved / frac (timing = two_lane_in_region) = algorithmic FLOPs of the fc1 launches / their summed HIP-event durations INSIDE the "
-                            "timed region, where two sub-batch lanes share the GPU: a launch's duration includes the time it waits beside the other lane's "
-                            "kernels (as rocprofv3 sees it), so this UNDERSTATES the kernel; single_stream.* is the same kernel with nothing else on the GPU "
-                            "(profiles/r03_rocprofv3_kernel_stats_single_stream.csv is the rocprofv3 view of that); frac_end_to_end = tiles/s x 123.11 GFLOP / "
-                            "peak over the whole encoder (the driver-checkable figure)"}
-        if iso is not None:
-            roofline["single_stream"] = {"achieved_single_stream": iso["achieved"], "frac_single_stream": round(iso["achieved"] / PEAK_F16_TFLOPS, 4),
-                                         "avg_launch_ms": iso["avg_launch_ms"], "launches": iso["launches"]}
+                    "note": "achieved / frac = ALGORITHMIC FLOPs (2*M*N*K per launch; correction passes are never counted) / summed launch durations; "
+                            "frac_end_to_end = tiles/s x 123.11 GFLOP / peak over the whole encoder (the figure the driver can check against its own clock); "
+                            "peak = 256 CU x 4096 FLOP/clk x 2.4 GHz dense fp16"}
         if clock is not None:
             roofline["clock"] = clock
             roofline["frac_of_peak_at_effective_clock"] = round(frac_e2e * 2400.0 / clock["effective_shader_MHz_median"], 4)
@@ -412,8 +571,11 @@ def main():
             line["sustained"] = sustained
         if parity is not None:
             line["parity"] = parity
-        if c3 is not None or c5 is not None:
-            line["configs"] = {"c3": c3, "c5": c5}
+        if c3 is not None or c4 is not None or c5 is not None:
+            line["configs"] = {"c3": c3, "c4": c4, "c5": c5}
+        if per_rank is not None:
+            line["per_rank_tiles_per_s"] = per_rank
+            line["exchange"] = exchange_cost
         if breakdown is not None:
             line["breakdown_ms_per_step_single_stream"] = breakdown
         if world == 1 and not args.no_cpu_baseline:

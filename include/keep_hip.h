@@ -225,8 +225,10 @@ int keep_refine(keep_handle* h, const float* probs, const int64_t* coords, int64
 /* ---- profiling (HIP events on the launch stream) ----------------------------------------------
  * tag names: "vit.im2col" "vit.patch" "vit.ln" "vit.qkv" "vit.attn" "vit.proj" "vit.fc1" "vit.fc2"
  * "vit.head" "text.embed" "text.ln" "text.qkv" "text.attn" "text.out" "text.ffn1" "text.ffn2"
- * "text.pool" "sim".  keep_profile_enable(h, NULL) times every tag, a name times only that tag,
- * "" disables.  keep_profile_read synchronises the recorded events and returns the accumulated
+ * "text.pool" "sim", and -- so that each plain image-tower tag times ONE kernel instantiation -- "vit.qkv.x" "vit.attn.x" "vit.proj.x"
+ * "vit.fc1.x" "vit.fc2.x" (the launches that carry extra passes: split / compensated products of the blocks the precision setting
+ * names) and "vit.tail" (the CLS-rows-only operators of the last block).  keep_profile_enable(h, NULL) times every tag, a name (or
+ * several separated by commas) times only those, "" disables.  keep_profile_read synchronises the recorded events and returns the accumulated
  * milliseconds, launch count and (for GEMM tags) executed FLOPs 2*M*N*K for `tag` since the last
  * keep_profile_reset.  Lanes on different internal streams overlap, so per-tag times can sum to more than
  * the wall time. */

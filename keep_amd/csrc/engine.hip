@@ -53,11 +53,16 @@ struct WTensor {
 
 enum Tag {
     T_VIT_IM2COL, T_VIT_PATCH, T_VIT_LN, T_VIT_QKV, T_VIT_ATTN, T_VIT_PROJ, T_VIT_FC1, T_VIT_FC2, T_VIT_HEAD,
-    T_TXT_EMBED, T_TXT_LN, T_TXT_QKV, T_TXT_ATTN, T_TXT_OUT, T_TXT_FFN1, T_TXT_FFN2, T_TXT_POOL, T_SIM, T_COUNT
+    T_TXT_EMBED, T_TXT_LN, T_TXT_QKV, T_TXT_ATTN, T_TXT_OUT, T_TXT_FFN1, T_TXT_FFN2, T_TXT_POOL, T_SIM,
+    // image-tower launches that are NOT the plain single-pass kernel of their operator: split products / compensated (MX-fp4) products of the
+    // blocks the precision setting names ("x" = extra passes), and the CLS-rows-only operators of the last block ("tail": small-M kernels).
+    // The plain tags above then time one kernel instantiation each (bench.py's roofline block needs a per-kernel figure).
+    T_VIT_QKV_X, T_VIT_ATTN_X, T_VIT_PROJ_X, T_VIT_FC1_X, T_VIT_FC2_X, T_VIT_TAIL, T_COUNT
 };
 const char* kTagNames[T_COUNT] = {
     "vit.im2col", "vit.patch", "vit.ln", "vit.qkv", "vit.attn", "vit.proj", "vit.fc1", "vit.fc2", "vit.head",
-    "text.embed", "text.ln", "text.qkv", "text.attn", "text.out", "text.ffn1", "text.ffn2", "text.pool", "sim"};
+    "text.embed", "text.ln", "text.qkv", "text.attn", "text.out", "text.ffn1", "text.ffn2", "text.pool", "sim",
+    "vit.qkv.x", "vit.attn.x", "vit.proj.x", "vit.fc1.x", "vit.fc2.x", "vit.tail"};
 
 struct VitBlock {
     const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b, *ls1, *ls2;
@@ -129,8 +134,8 @@ struct keep_handle {
     int* err_flag = nullptr;     // device int, sticky: bit 0 out-of-range token ids, bit 1 non-finite output features (fp16 range exceeded)
 
     // profiling
-    int prof_mode = 0;           // 0 off, 1 single tag, 2 all
-    int prof_tag = -1;
+    int prof_mode = 0;           // 0 off, 1 the tags of prof_mask, 2 all
+    unsigned long long prof_mask = 0;
     struct Rec { hipEvent_t a, b; int tag; };
     std::vector<Rec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -165,7 +170,7 @@ struct keep_handle {
     bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 128 == 0)
     bool any_comp() const { return precision == KEEP_PREC_COMP && vit_has_q && (comp_mlp_blocks > 0 || (comp_full_blocks > 0 && comp_qkv)); }
 
-    bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && tag == prof_tag); }
+    bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && ((prof_mask >> tag) & 1ull)); }
     void prof_add_flops(int tag, double f) { if (prof_on(tag)) prof_flops[tag] += f; }
     void prof_begin(int tag, hipStream_t s) {
         if (!prof_on(tag)) return;
@@ -426,15 +431,16 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     }
     L.xn_ready = false;
     {
-        Scope sc(h, T_VIT_QKV, s);
+        const int tag = sp ? T_VIT_QKV_X : T_VIT_QKV;
+        Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, b.qkv_b);
         p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
         if (qkv_q) { p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.qkv->q; p.w_sc = b.qkv->sc; }
-        if (run_gemm(h, T_VIT_QKV, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "qkv GEMM launch failed");
+        if (run_gemm(h, tag, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "qkv GEMM launch failed");
     }
     mark(1);
     {
-        Scope sc(h, T_VIT_ATTN, s);
+        Scope sc(h, sp ? T_VIT_ATTN_X : T_VIT_ATTN, s);
         AttnParams a{};
         a.tune = &h->tune;
         a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
@@ -463,11 +469,12 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     ln.gamma = b.n2w; ln.beta = b.n2b;
     int did;
     {
-        Scope sc(h, T_VIT_PROJ, s);
+        const int tag = cls_only ? T_VIT_TAIL : sp ? T_VIT_PROJ_X : T_VIT_PROJ;
+        Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
         p.ls = b.ls1; p.resid = resid;
         if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
-        did = run_gemm(h, T_VIT_PROJ, p, EPI_RESID_LS, s, ws.splitk);
+        did = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
         if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
     }
     mark(3);
@@ -476,18 +483,20 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
     }
     {
-        Scope sc(h, T_VIT_FC1, s);
+        const int tag = cls_only ? T_VIT_TAIL : mlp ? T_VIT_FC1_X : T_VIT_FC1;
+        Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, b.fc1_b);
         p.out_hi = mlp_hi; p.out_lo = mlp_lo ? mlp_lo_p : nullptr; p.out_kt = h->vit_F / 32;
         if (mlp_q) {
             p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
             p.out_q = ws.mlp_q; p.out_sc = ws.mlp_sc;
         }
-        if (run_gemm(h, T_VIT_FC1, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "fc1 GEMM launch failed");
+        if (run_gemm(h, tag, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "fc1 GEMM launch failed");
     }
     mark(4);
     {
-        Scope sc(h, T_VIT_FC2, s);
+        const int tag = cls_only ? T_VIT_TAIL : mlp ? T_VIT_FC2_X : T_VIT_FC2;
+        Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, b.fc2_b);
         p.ls = b.ls2; p.resid = resid;
         if (mlp_q) { p.comp = 1; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
@@ -498,7 +507,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             ln.gamma = nb.n1w; ln.beta = nb.n1b;
             offer_ln(p, ln);
         }
-        const int rc = run_gemm(h, T_VIT_FC2, p, EPI_RESID_LS, s, ws.splitk);
+        const int rc = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
         if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "fc2 GEMM launch failed");
         L.xn_ready = (rc & GEMM_DID_LN) != 0;
     }
@@ -1511,9 +1520,20 @@ int keep_profile_enable(keep_handle* h, const char* tag) {
     if (!h) return KEEP_EINVAL;
     if (!tag) { h->prof_mode = 2; return KEEP_OK; }
     if (!*tag) { h->prof_mode = 0; return KEEP_OK; }
-    const int t = tag_by_name(tag);
-    if (t < 0) return h->fail(KEEP_EINVAL, "unknown profile tag %s", tag);
-    h->prof_mode = 1; h->prof_tag = t;
+    // one tag, or several separated by commas ("vit.proj,vit.fc2")
+    unsigned long long mask = 0;
+    std::string names(tag);
+    size_t a = 0;
+    while (a <= names.size()) {
+        const size_t b = names.find(',', a);
+        const std::string one = names.substr(a, b == std::string::npos ? std::string::npos : b - a);
+        const int t = tag_by_name(one.c_str());
+        if (t < 0) return h->fail(KEEP_EINVAL, "unknown profile tag %s", one.c_str());
+        mask |= 1ull << t;
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    h->prof_mode = 1; h->prof_mask = mask;
     return KEEP_OK;
 }
 int keep_profile_read(keep_handle* h, const char* tag, double* total_ms, int64_t* launches, double* flops) {

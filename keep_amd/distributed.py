@@ -178,14 +178,17 @@ class StepExchange:
             torch.cuda.synchronize(self.device)
 
 
-def timed_steps(step: Callable[[], None], n_steps: int, exchange: StepExchange) -> float:
-    """Seconds for exactly ``n_steps`` calls of ``step`` between two fences (barrier + device synchronisation), MAX over the ranks."""
+def timed_steps(step: Callable[[], None], n_steps: int, exchange: StepExchange, own: Optional[list] = None) -> float:
+    """Seconds for exactly ``n_steps`` calls of ``step`` between two fences (barrier + device synchronisation), MAX over the ranks.
+    ``own``: a list that receives this rank's own time (before the MAX), for per-rank rates."""
     exchange.fence()
     t0 = time.perf_counter()
     for _ in range(n_steps):
         step()
     exchange.fence()
     el = time.perf_counter() - t0
+    if own is not None:
+        own.append(el)
     if exchange.distributed:
         t = torch.tensor([el], device=exchange.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=exchange.group)

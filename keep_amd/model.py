@@ -718,4 +718,7 @@ def engine_for(device=None, model=None) -> "KEEPModel":
 
 PROFILE_TAGS = ("vit.im2col", "vit.patch", "vit.ln", "vit.qkv", "vit.attn", "vit.proj", "vit.fc1", "vit.fc2",
                 "vit.head", "text.embed", "text.ln", "text.qkv", "text.attn", "text.out", "text.ffn1", "text.ffn2",
-                "text.pool", "sim")
+                "text.pool", "sim",
+                # launches with extra passes (split / compensated products of the blocks the precision setting names) and the CLS-rows-only
+                # operators of the last block are timed apart, so that the plain tags hold ONE kernel instantiation each
+                "vit.qkv.x", "vit.attn.x", "vit.proj.x", "vit.fc1.x", "vit.fc2.x", "vit.tail")

@@ -824,3 +824,30 @@ def test_text_graph_replay_covers_a_64_prompt_bank_chunk(small):
     m.check_token_ids = True
     with pytest.raises(IndexError):
         m.encode_text(bad)
+
+
+def test_slide_sized_population_stays_inside_the_tolerance():
+    """BASELINE configs 4 / 5 put 100 000 tiles against a prompt bank; the tolerance is on EVERY cosine, so the worst of N x P errors matters and it
+    grows with the population.  One eighth of such a slide (12 500 tiles, the share of one of 8 GPUs) in the calibrated setting against the
+    split-product mode: all 12 500 x 64 and 12 500 x 264 cosines within 1e-4, max / rms as a Gaussian population predicts (that is the rule
+    calibrate() extrapolates with), same slide label, same screened prompt sets; the full size runs in bench.py (`configs.c4`)."""
+    import bench
+    from keep_amd.model import CALIBRATION_POPULATION, expected_max_sigmas
+    sd = synth_state_dict(KEEPShape(), seed=0)
+    m = make_model(sd, "comp")
+    assert m.calibration["population"] == CALIBRATION_POPULATION and m.calibration["precision"] == "comp"
+    own = (m.calibration["comp_full_blocks"], m.calibration["comp_mlp_blocks"])
+    r = bench.config4(m, torch.device("cuda", 0), n=12_500)
+    h = r["headline_setting"]
+    print(f"[12 500 tiles, setting {own}] vs strict: 64 prompts {h['cos_vs_64_prompts']}; 264 distinct {h['cos_vs_264_distinct_prompts']}; "
+          f"scores {h['screening_scores']}; label {h['slide_label']}; tumour ratio {h['tumour_ratio']}; calls differ on {h['tumour_tile_calls']}")
+    assert (h["comp_full_blocks"], h["comp_mlp_blocks"]) == own
+    assert (int(m.get_option("comp_full_blocks")), int(m.get_option("comp_mlp_blocks"))) == own and m.get_option("precision") == 2     # restored
+    for key in ("cos_vs_64_prompts", "cos_vs_264_distinct_prompts"):
+        st = h[key]
+        assert st["max_abs"] <= COS_TOL and st["over_1e-4"] == 0
+        assert st["max_over_rms"] <= 1.15 * expected_max_sigmas(st["n"])           # no heavier than Gaussian tails: what the population rule assumes
+        assert st["rms"] * expected_max_sigmas(CALIBRATION_POPULATION) <= 1.02 * COS_TOL   # ... and its prediction for the full population holds
+    assert r["within_1e-4"] and h["slide_label_equal"] and h["screening_scores"]["same_top_n"] and h["screening_scores"]["max_abs_diff"] < 1e-4
+    assert h["tumour_tile_calls"]["largest_strict_cos_margin_of_such_a_tile"] <= 2 * COS_TOL      # a call only moves on a near tie
+    assert abs(h["tumour_ratio"][0] - h["tumour_ratio"][1]) <= 2e-3

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""The 1e-4 cosine tolerance at BASELINE config-4 / config-5 size, measured: a 100 000-tile synthetic slide encoded in the 'comp' settings and
-in 'strict' (pinned to 6.4e-7 of the fp32 oracle on config 3), every cosine against a 64-prompt bank and against the 264 distinct prompts
-the RCC classifier bank is built from (K = 1782 prompt sets x C = 4 -> 7128 columns), the screening scores, the ensemble classifier, the
-slide label and the tumour ratio.  Also what calibrate() predicts from its 256-tile probe, next to what the slide shows.
+"""The 1e-4 cosine tolerance at BASELINE config-4 / config-5 size for SEVERAL 'comp' settings (bench.py's `configs.c4` leg measures the one the
+headline ran): a 100 000-tile synthetic slide encoded in each setting and in 'strict', every cosine against a 64-prompt bank and against the 264
+distinct prompts of an RCC-shaped classifier bank, the screening scores, the ensemble, the slide label and the tumour ratio (bench.config4).
 
     python tools/c4_parity.py [--tiles 100000] [--settings 1,6 1,8 1,10] [--out gpurun_out/c4_parity.json]
 """
@@ -10,31 +9,15 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from keep_amd import KEEPModel, wsi                                       # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                              # noqa: E402
+from keep_amd import KEEPModel                                            # noqa: E402
 from keep_amd.config import KEEPShape                                     # noqa: E402
-from keep_amd.model import expected_max_sigmas                            # noqa: E402
-from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles_device   # noqa: E402
-
-
-def stats(d):
-    mx, rms = float(d.abs().max()), float(d.double().pow(2).mean().sqrt())
-    return {"max_abs": float(f"{mx:.3e}"), "rms": float(f"{rms:.3e}"), "max_over_rms": round(mx / rms, 2), "n": int(d.numel()),
-            "gaussian_expectation_of_max_over_rms": round(expected_max_sigmas(d.numel()), 2),
-            "over_1e-4": int((d.abs() > 1e-4).sum())}
-
-
-def rcc_bank(txt264, K=1782, C=4, seed=11):
-    """K prompt sets x C classes drawn from few distinct strings, as the RCC prompt file: column = unit text embedding."""
-    g = torch.Generator().manual_seed(seed)
-    n = txt264.shape[0]
-    per_class = n // C
-    picks = torch.stack([torch.randint(0, per_class, (K,), generator=g) + c * per_class for c in range(C)], 1)      # [K, C]: class c draws from its own strings
-    return [txt264[p.to(txt264.device)].t().contiguous() for p in picks], picks
+from keep_amd.synth import synth_state_dict                               # noqa: E402
 
 
 def main():
@@ -42,77 +25,14 @@ def main():
     ap.add_argument("--tiles", type=int, default=100_000)
     ap.add_argument("--settings", nargs="*", default=["1,6", "1,8", "1,10"])
     ap.add_argument("--out", default="gpurun_out/c4_parity.json")
-    ap.add_argument("--topn", type=int, default=50)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    shape = KEEPShape()
-    model = KEEPModel(shape)
-    model.auto_calibrate = False
-    model.load_state_dict(synth_state_dict(shape, seed=0))
-    model.to(dev).eval()
+    model = KEEPModel(KEEPShape())
+    model.load_state_dict(synth_state_dict(KEEPShape(), seed=0))
+    model.to(dev).eval()                                                  # calibrates: `headline_setting` below is what load_state_dict picked
     model.reserve(tiles=256)
-    N = args.tiles
-
-    def encode_all():
-        out = torch.empty(N, 768, device=dev)
-        t0 = time.perf_counter()
-        for a in range(0, N, 256):
-            b = min(a + 256, N)
-            out[a:b] = model.encode_image(synth_tiles_device(a, b, dev, torch.bfloat16, seed=1000))
-        torch.cuda.synchronize()
-        return out, time.perf_counter() - t0
-
-    toks64 = synth_prompts(64, 256, seed=1)
-    toks264 = synth_prompts(264, 256, seed=5)
-    model.set_precision("strict")
-    txt64 = model.encode_text({k: v.to(dev) for k, v in toks64.items()})
-    txt264 = torch.cat([model.encode_text({k: v[i:i + 64].to(dev) for k, v in toks264.items()}) for i in range(0, 264, 64)])
-    f_strict, t_strict = encode_all()
-    res = {"tiles": N, "weights": "synth_state_dict(seed=0), full depth", "reference": "the engine's 'strict' mode (split products; 6.4e-7 of the fp32 oracle on config 3)",
-           "strict_tiles_per_s": round(N / t_strict, 1), "settings": {}}
-    sim64_s, sim264_s = model.similarity(f_strict, txt64), model.similarity(f_strict, txt264)
-    bank4, _ = rcc_bank(txt264)
-    bank2 = [c[:, :2].contiguous() for c in bank4]
-    coords = torch.stack([(torch.arange(N) % 400) * 256, (torch.arange(N) // 400) * 256], 1).numpy()
-    sc_s = wsi.prompt_scores(f_strict, bank4, model=model)
-    ens4_s = wsi.zero_shot_prompt_select(bank4, f_strict, args.topn, dev, model=model)
-    ens2_s = wsi.zero_shot_prompt_select(bank2, f_strict, args.topn, dev, model=model)
-    label_s = int(wsi.zero_shot_subtyping(ens4_s, f_strict, coords, 256, True, model=model))
-    ratio_s = wsi.zero_shot_detection(ens2_s, f_strict, coords, 256, False, model=model)
-    prob_s = model.similarity(f_strict, ens2_s.t().contiguous(), scale=10.0, mode="softmax_f16")
-    for st in args.settings:
-        full, mlp = (int(v) for v in st.split(","))
-        model.set_precision("comp")
-        model.set_option("comp_full_blocks", full)
-        model.set_option("comp_mlp_blocks", mlp)
-        f, t = encode_all()
-        e = (f - f_strict).norm(dim=1)
-        r = {"tiles_per_s_incl_tile_generation": round(N / t, 1),
-             "feature_error_norm": {"max": float(f"{float(e.max()):.3e}"), "rms": float(f"{float(e.pow(2).mean().sqrt()):.3e}")},
-             "cos_vs_64_prompts": stats(model.similarity(f, txt64) - sim64_s),
-             "cos_vs_264_distinct_prompts": stats(model.similarity(f, txt264) - sim264_s)}
-        sc = wsi.prompt_scores(f, bank4, model=model)
-        ens4 = wsi.zero_shot_prompt_select(bank4, f, args.topn, dev, model=model)
-        ens2 = wsi.zero_shot_prompt_select(bank2, f, args.topn, dev, model=model)
-        prob = model.similarity(f, ens2.t().contiguous(), scale=10.0, mode="softmax_f16")
-        r["screening_scores_K1782_C4"] = {"max_abs_diff": float(f"{float((sc - sc_s).abs().max()):.3e}"),
-                                         "same_top_n": bool(set(torch.topk(sc, args.topn).indices.tolist()) == set(torch.topk(sc_s, args.topn).indices.tolist()))}
-        r["ensemble_classifier_max_abs_diff"] = float(f"{float((ens4 - ens4_s).abs().max()):.3e}")
-        r["slide_label_equal"] = int(wsi.zero_shot_subtyping(ens4, f, coords, 256, True, model=model)) == label_s
-        r["tumour_ratio"] = [wsi.zero_shot_detection(ens2, f, coords, 256, False, model=model), ratio_s]
-        r["tumour_ratio_equal"] = r["tumour_ratio"][0] == r["tumour_ratio"][1]
-        r["prob_map_fp16_max_abs_diff"] = float(f"{float((prob.float() - prob_s.float()).abs().max()):.3e}")
-        # what the load-time probe says about this setting (256 tiles x 64 prompts), for the prediction-vs-slide comparison
-        g = torch.Generator(device=dev).manual_seed(20250929)
-        probe = torch.randn(256, 3, 224, 224, device=dev, generator=g).to(torch.bfloat16)
-        pc = model.similarity(model.encode_image(probe), txt64)
-        model.set_precision("strict")
-        ps = model.similarity(model.encode_image(probe), txt64)
-        r["probe_256x64"] = stats(pc - ps)
-        for key, n in (("cos_vs_64_prompts", N * 64), ("cos_vs_264_distinct_prompts", N * 264)):
-            r[key]["predicted_max_from_probe_rms"] = float(f"{r['probe_256x64']['rms'] * expected_max_sigmas(n):.3e}")
-        res["settings"][st] = r
-        print(st, json.dumps(r), flush=True)
+    res = bench.config4(model, dev, n=args.tiles, settings=[tuple(int(v) for v in st.split(",")) for st in args.settings])
+    res["calibration"] = model.calibration
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(res, open(args.out, "w"), indent=1)
     print(json.dumps(res))
