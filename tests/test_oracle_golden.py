@@ -32,7 +32,10 @@ def test_image_tower_matches_golden(golden_dir, depth):
         cls = O.vit_forward(sd, x, depth)
         feat = O.encode_image(sd, x)
     assert np.abs(cls.numpy() - g["cls"]).max() < 2e-4          # LN'd CLS token, |values| ~ 1
-    assert np.abs(feat.numpy() - g["features"]).max() < 2e-6    # unit-norm 768-d features
+    assert np.abs(feat.numpy() - g["features"]).max() < 2e-6    # unit-norm 768-d features (pin 1: transformers' Dinov2Model as ViT-L/16)
+    # pin 2: timm's module tree on the ATen ops timm dispatches (tools/make_golden.py `_TimmViT`), loaded strictly from the release key layout
+    assert np.abs(feat.numpy() - g["features_aten_timm"]).max() < 1e-6
+    assert float(g["pins_dfeat"]) < 1e-6 and float(g["oracle_dfeat_aten_timm"]) < 1e-6
     assert np.allclose(np.linalg.norm(feat.numpy(), axis=1), 1.0, atol=1e-6)
 
 

@@ -422,6 +422,26 @@ def test_full_depth_image_tower_vs_golden(golden_dir, text_bank, precision):
     assert torch.equal((out @ text_bank.t()).argmax(1), (ref @ text_bank.t()).argmax(1))
 
 
+@pytest.mark.parametrize("precision", ["strict", "comp"])
+def test_bench_weights_vs_both_image_tower_pins(golden_dir, text_bank, precision):
+    """The weights bench.py runs on (seed 0), 8 tiles, against BOTH independent fp32 implementations the oracle is pinned to
+    (tools/make_golden.py vit24_bench): transformers' Dinov2Model configured as ViT-L/16, and the module tree of timm's
+    vit_large_patch16_224 on the ATen ops timm dispatches (F.conv2d / F.layer_norm / F.scaled_dot_product_attention / F.gelu / F.linear),
+    loaded strictly from the release key layout.  The fixture also records how far the oracle and the two pins are from each other (< 3e-7)."""
+    g = np.load(os.path.join(golden_dir, "vit_d24_bench.npz"))
+    assert float(g["oracle_dfeat"]) < 1e-6 and float(g["oracle_dfeat_aten_timm"]) < 1e-6 and float(g["pins_dfeat"]) < 1e-6
+    sd = synth_state_dict(KEEPShape(), seed=int(g["weight_seed"]), text=False)
+    x = synth_tiles(int(g["batch"]), seed=int(g["tile_seed"]))
+    m = make_model(sd, precision)
+    out = m.encode_image(x)
+    for name in ("features", "features_aten_timm"):
+        ref = torch.from_numpy(g[name])
+        dcos = (out @ text_bank.t() - ref @ text_bank.t()).abs().max().item()
+        print(f"[bench weights {precision} vs {name}] max|dfeat|={(out - ref).abs().max():.3e} max|dcos|={dcos:.3e}")
+        assert dcos < tol(precision, 5e-6)
+        assert torch.equal((out @ text_bank.t()).argmax(1), (ref @ text_bank.t()).argmax(1))
+
+
 @pytest.mark.parametrize("precision", MODES)
 def test_full_depth_text_tower_vs_golden(golden_dir, text_bank, precision):
     g = np.load(os.path.join(golden_dir, "bert_l12.npz"))

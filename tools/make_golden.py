@@ -7,7 +7,11 @@ Runs ONLY in the build container (needs `transformers` and /root/reference):
                   quick_start/keep_inference.py:49-50)
   image tower  <- transformers.Dinov2Model configured as ViT-L/16 + LayerScale
                   (independent implementation of timm vit_large_patch16_224's
-                  block arithmetic; timm is not installed here)
+                  block arithmetic; timm is not installed here), AND a module tree
+                  shaped like timm's own (PatchEmbed / Attention with the fused qkv
+                  reshape-permute / LayerScale / Mlp) on the ATen ops timm dispatches
+                  (F.conv2d, F.layer_norm, F.scaled_dot_product_attention, F.gelu,
+                  F.linear), loaded strictly from the release key layout
   WSI logic    <- /root/reference/WSI_evaluation/{utils,subtyping_utils,
                   detection_utils,segment_utils}.py imported as-is (h5py and
                   openslide stubbed: they are import-time only for these functions)
@@ -77,6 +81,104 @@ def hf_dinov2_from_sd(sd, depth):
     return m
 
 
+# --------------------------------------------------------------------------
+# Second, independent pin of the image tower: the module tree timm's `vit_large_patch16_224` builds with the reference's ctor arguments
+# (quick_start/keep_inference.py:32-40), written here from timm 1.0.15's published module semantics on the ATen ops timm dispatches:
+# PatchEmbed = F.conv2d stride 16 -> flatten(2).transpose(1, 2); _pos_embed = cat(cls, x) + pos_embed; Block = x + ls1(attn(norm1(x))), x + ls2(mlp(norm2(x)));
+# Attention = fused nn.Linear qkv -> reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4) -> F.scaled_dot_product_attention -> transpose(1, 2).reshape -> proj;
+# LayerScale = x * gamma; Mlp = fc1 -> nn.GELU (erf) -> fc2; norm = nn.LayerNorm(eps 1e-6); global_pool 'token'; head Identity (num_classes = 0).
+# Parameter names ARE the release's state_dict keys under `visual.`, so the seeded state_dict loads with strict=True -- which pins the
+# key layout as well.  Not timm (absent offline), but fused-kernel ATen arithmetic instead of the oracle's hand-written matmul / softmax / erf formulas.
+# --------------------------------------------------------------------------
+class _TimmPatchEmbed(torch.nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = torch.nn.Conv2d(3, dim, kernel_size=16, stride=16)
+
+    def forward(self, x):
+        return torch.nn.functional.conv2d(x, self.proj.weight, self.proj.bias, stride=16).flatten(2).transpose(1, 2)
+
+
+class _TimmAttention(torch.nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads, self.head_dim = heads, dim // heads
+        self.qkv = torch.nn.Linear(dim, dim * 3, bias=True)
+        self.proj = torch.nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.unbind(0)
+        x = torch.nn.functional.scaled_dot_product_attention(q, k, v)          # timm's fused_attn path, scale = head_dim ** -0.5
+        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+
+
+class _TimmLayerScale(torch.nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = torch.nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class _TimmMlp(torch.nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1, self.act, self.fc2 = torch.nn.Linear(dim, hidden), torch.nn.GELU(), torch.nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _TimmBlock(torch.nn.Module):
+    def __init__(self, dim, heads, hidden):
+        super().__init__()
+        self.norm1, self.attn, self.ls1 = torch.nn.LayerNorm(dim, eps=1e-6), _TimmAttention(dim, heads), _TimmLayerScale(dim)
+        self.norm2, self.mlp, self.ls2 = torch.nn.LayerNorm(dim, eps=1e-6), _TimmMlp(dim, hidden), _TimmLayerScale(dim)
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class _TimmViT(torch.nn.Module):
+    def __init__(self, depth, dim=1024, heads=16, hidden=4096, tokens=197):
+        super().__init__()
+        self.cls_token = torch.nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = torch.nn.Parameter(torch.zeros(1, tokens, dim))
+        self.patch_embed = _TimmPatchEmbed(dim)
+        self.blocks = torch.nn.Sequential(*[_TimmBlock(dim, heads, hidden) for _ in range(depth)])
+        self.norm = torch.nn.LayerNorm(dim, eps=1e-6)
+
+    def forward_tokens(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        return self.norm(self.blocks(x))
+
+    def forward(self, x):
+        return self.forward_tokens(x)[:, 0]                                       # global_pool = 'token', head = Identity
+
+
+class _KeepImageSide(torch.nn.Module):
+    """`visual` + `visual_head` of the reference's KEEPModel (keep_inference.py:32-46) and its encode_image (:54-58)."""
+
+    def __init__(self, depth):
+        super().__init__()
+        self.visual = _TimmViT(depth)
+        self.visual_head = torch.nn.Sequential(torch.nn.Linear(1024, 768), torch.nn.GELU(), torch.nn.Linear(768, 768))
+
+    def encode_image(self, image_inputs):
+        return torch.nn.functional.normalize(self.visual_head(self.visual(image_inputs)), dim=-1)
+
+
+def aten_timm_from_sd(sd, depth):
+    m = _KeepImageSide(depth).eval()
+    m.load_state_dict({k: v for k, v in sd.items() if k.startswith("visual")}, strict=True)      # the release's key layout, strictly
+    return m
+
+
 def golden_vit(depth: int, batch: int, seed: int, name: str = None):
     shape = small_shape(vit_depth=depth) if depth != 24 else KEEPShape()
     sd = synth_state_dict(shape, seed=seed, text=False)
@@ -92,15 +194,21 @@ def golden_vit(depth: int, batch: int, seed: int, name: str = None):
         feat_hf = torch.nn.functional.normalize(head(cls_hf), dim=-1)    # keep_inference.py:56
         tok_or = O.vit_tokens(sd, x, depth)
         feat_or = O.encode_image(sd, x)
+        at = aten_timm_from_sd(sd, depth)
+        tok_at, feat_at = at.visual.forward_tokens(x), at.encode_image(x)
     d_tok = float((tok_or - tok_hf).abs().max())
     d_feat = float((feat_or - feat_hf).abs().max())
-    print(f"[vit d{depth}] oracle vs Dinov2: max|dtok|={d_tok:.3e} max|dfeat|={d_feat:.3e}")
+    a_tok, a_feat = float((tok_or - tok_at).abs().max()), float((feat_or - feat_at).abs().max())
+    x_feat = float((feat_at - feat_hf).abs().max())
+    print(f"[vit d{depth}] oracle vs Dinov2: max|dtok|={d_tok:.3e} max|dfeat|={d_feat:.3e}; oracle vs ATen-op timm restatement: max|dtok|={a_tok:.3e} "
+          f"max|dfeat|={a_feat:.3e}; the two pins against each other: {x_feat:.3e}")
     assert d_tok < 5e-4 and d_feat < 2e-6, "oracle image tower disagrees with Dinov2-as-ViT-L"
+    assert a_tok < 5e-4 and a_feat < 1e-6, "oracle image tower disagrees with the ATen-op restatement of timm's vit_large_patch16_224"
     np.savez_compressed(os.path.join(GOLD, name or f"vit_d{depth}.npz"),
                         depth=depth, batch=batch, weight_seed=seed, tile_seed=seed + 100,
                         tiles_checksum=checksum(x), qkv0_checksum=checksum(sd["visual.blocks.0.attn.qkv.weight"]),
-                        cls=cls_hf.numpy(), features=feat_hf.numpy(),
-                        oracle_dtok=d_tok, oracle_dfeat=d_feat)
+                        cls=cls_hf.numpy(), features=feat_hf.numpy(), features_aten_timm=feat_at.numpy(),
+                        oracle_dtok=d_tok, oracle_dfeat=d_feat, oracle_dtok_aten_timm=a_tok, oracle_dfeat_aten_timm=a_feat, pins_dfeat=x_feat)
 
 
 # --------------------------------------------------------------------------
