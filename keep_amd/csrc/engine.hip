@@ -1370,8 +1370,10 @@ int keep_classify(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, 
     if (count == 0) return check_launch(h, "classify");
     const int saved = h->precision;
     h->precision = KEEP_PREC_STRICT;                                    // per call, no option epoch: graph keys carry the precision
-    for (int64_t c0 = 0; c0 < count && !rc; c0 += stage_tiles) {
-        const int n = (int)((count - c0) < stage_tiles ? (count - c0) : stage_tiles);
+    // equal sub-batches (272 flagged tiles: 136 + 136, not 256 + 16 -- a 16-tile encode is latency-bound and costs a third of a 256-tile one)
+    const int64_t parts = (count + stage_tiles - 1) / stage_tiles, per = (count + parts - 1) / parts;
+    for (int64_t c0 = 0; c0 < count && !rc; c0 += per) {
+        const int n = (int)((count - c0) < per ? (count - c0) : per);
         launch_gather_tiles(pixels, (int64_t)tile_bytes, list + c0, n, b + o_stage, s);
         rc = encode_image_run(h, b + o_stage, pix_dtype, n, (float*)(b + o_f2), s);
         if (!rc) launch_scatter_rows((const float*)(b + o_f2), list + c0, n, D, feats, s);

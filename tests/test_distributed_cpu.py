@@ -116,8 +116,18 @@ def _bench_loop_worker(rank, world, port, q):
                               for r in range(world)])
             ok = ok and torch.equal(ex.gathered(i), want)
         # MAX over ranks: a slow rank sets everybody's time
-        slow = timed_steps(lambda: time.sleep(0.05 if rank == world - 1 else 0.0) or step(), 3, ex)
-        ok = ok and slow >= 0.15
+        own = []
+        slow = timed_steps(lambda: time.sleep(0.05 if rank == world - 1 else 0.0) or step(), 3, ex, own)
+        ok = ok and slow >= 0.15 and len(own) == 1 and 0 < own[0] <= slow + 1e-6      # `own`: this rank's time before the MAX (per-rank rates)
+        # every rank must run the same engine setting (each calibrates on its own at load): agreement passes, one deviating rank raises EVERYWHERE
+        from keep_amd.distributed import assert_same_setting
+        rows = assert_same_setting([2, 1, 8], "precision setting")
+        ok = ok and len(rows) == world and all(r == [2.0, 1.0, 8.0] for r in rows)
+        try:
+            assert_same_setting([2, 1, 8 if rank else 6], "precision setting")
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "rank 0: [2.0, 1.0, 6.0]" in str(e)
         q.put((rank, bool(ok), el, slow))
     finally:
         dist.destroy_process_group()
@@ -147,6 +157,8 @@ def test_step_exchange_without_a_process_group():
         i = ex.submit(torch.full((4, 3), float(k)))
         assert torch.equal(ex.gathered(i), torch.full((4, 3), float(k)))
     assert timed_steps(lambda: ex.submit(torch.zeros(4, 3)), 2, ex) > 0
+    from keep_amd.distributed import assert_same_setting
+    assert assert_same_setting([1, 2.5]) == [[1.0, 2.5]]                 # no process group: trivially in agreement
 
 
 def test_empty_slide_and_bad_arguments():

@@ -66,6 +66,10 @@ def test_bench_distributed_leg_runs_on_nccl():
     line = json.loads(r.stdout.strip().splitlines()[-1])          # the JSON line is the last thing on stdout, after RCCL's banner
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert "RCCL" in line["config"]["exchange"]
+    # the N > 1 additions: every rank's own rate, and what the exchange costs on the critical path (same steps without it)
+    assert len(line["per_rank_tiles_per_s"]) == 1 and line["per_rank_tiles_per_s"][0] > 0
+    assert set(line["exchange"]) >= {"ms_per_step_with_exchange", "ms_per_step_encode_only", "exposed_ms_per_step", "bytes_gathered_per_step"}
+    assert line["roofline"]["in_timed_region_two_lane"]["launches"] > 0
 
 
 def _rccl_worker(rank, world, port, n_tiles, q):

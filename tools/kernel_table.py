@@ -11,6 +11,7 @@ import csv, json, re, sys
 from collections import defaultdict
 
 stats_csv, pmc_csv, traffic_json, steps = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+bench_json = sys.argv[5] if len(sys.argv) > 5 else None        # optional: bench.py's line of the same build (HIP-event split of the proj / fc2 launches)
 M = 256 * 197                       # rows of a 256-tile step (one lane when streams = 1)
 PEAK_TF, PEAK_HBM = 2516.6, 8000.0
 # kernel-name pattern -> (label, algorithmic FLOP per launch or None, algorithmic bytes per launch or None, roofline)
@@ -44,6 +45,11 @@ traffic = json.load(open(traffic_json))
 tr_by_pat = {v["kernel"]: v for v in traffic.values()}
 
 total_ns = sum(t for _, t, _ in stats.values())
+# the fp32-residual kernel serves proj (K = 1024) and fc2 (K = 4096): as many fc2 launches as plain fc1 launches, the rest are proj
+RES, FC1 = "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>", "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>"
+c_res = next((v[0] for n, v in stats.items() if RES in n), 0)
+c_fc1 = next((v[0] for n, v in stats.items() if FC1 in n), 0)
+res_flop_avg = ((c_res - c_fc1) * G(1024, 1024) + c_fc1 * G(1024, 4096)) / c_res if c_res > c_fc1 > 0 else None
 print("| kernel | launches / step | avg µs | % of step | algorithmic rate | frac of roofline | matrix pipe busy | eff. clock (MHz) | HBM-side bytes / launch (÷ algorithmic) |")
 print("|---|---|---|---|---|---|---|---|---|")
 seen = 0.0
@@ -54,6 +60,9 @@ for pat, label, flop, abytes, roof in KERNELS:
     name, (calls, tot, avg) = hit[0]
     seen += tot
     rate = frac = "—"
+    if pat == RES and res_flop_avg:
+        flop = res_flop_avg
+        label += f" [{(c_res - c_fc1) / steps:.0f} proj + {c_fc1 / steps:.0f} fc2 launches per step]"
     if roof == "mfma" and flop:
         tf = flop / avg / 1e3
         rate, frac = f"{tf:.0f} TFLOP/s", f"{tf / PEAK_TF:.3f}"
@@ -74,6 +83,12 @@ for pat, label, flop, abytes, roof in KERNELS:
     if t:
         tb = f"{t['bytes_per_launch'] / 1e6:.0f} MB" + (f" ({t['traffic_over_algorithmic']}x)" if "traffic_over_algorithmic" in t else "")
     print(f"| `{label}` | {calls / steps:.1f} | {avg / 1e3:.1f} | {100 * tot / total_ns:.1f} | {rate} | {frac} | {busy} | {clk} | {tb} |")
+    if pat == RES and bench_json:
+        by = json.load(open(bench_json))["roofline"].get("by_operator", {})
+        for op, what in (("vit.proj", "— of which proj [M,1024] x [1024,1024] (HIP events, bench.py single-stream pass)"), ("vit.fc2", "— of which fc2 [M,4096] x [4096,1024]")):
+            if op in by:
+                o = by[op]
+                print(f"| {what} | {o['launches'] / 3:.0f} | {o['avg_launch_ms'] * 1e3:.1f} | | {o['achieved']:.0f} TFLOP/s | {o['frac']:.3f} | | | |")
 print(f"| everything else | | | {100 * (total_ns - seen) / total_ns:.1f} | | | | | |")
 print(f"\nstep = {total_ns / steps / 1e6:.2f} ms of kernel time on one stream ({steps:.0f} steps profiled); peaks: {PEAK_TF} TFLOP/s dense fp16 at 2.4 GHz, {PEAK_HBM:.0f} GB/s HBM.")
 print("`matrix pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); `eff. clock` = GRBM_GUI_ACTIVE / 8 / duration of the same dispatches "

@@ -25,6 +25,13 @@ TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "vit.fc1+
 M = 128 * 197
 ALGO = {"vit.fc1": 2 * (M * 1024 + 4096 * 1024) + 2 * M * 4096, "vit.qkv": 2 * (M * 1024 + 3072 * 1024) + 2 * M * 3072,
         "vit.attn": 2 * M * 3072 + 2 * M * 1024, "vit.ln": 4 * M * 1024 + 2 * M * 1024}
+# the fp32-residual kernel is launched for proj (K = 1024) and fc2 (K = 4096): as many fc2 launches as plain fc1 launches, the rest are proj
+B_PROJ = 2 * (M * 1024 + 1024 * 1024) + 8 * M * 1024
+B_FC2 = 2 * (M * 4096 + 4096 * 1024) + 8 * M * 1024
+n_all = sum(n for k, (v, n) in fetch.items() if TAGS["vit.proj+fc2"] in k)
+n_fc2 = sum(n for k, (v, n) in fetch.items() if TAGS["vit.fc1"] in k)
+if n_all > n_fc2 > 0:
+    ALGO["vit.proj+fc2"] = round(((n_all - n_fc2) * B_PROJ + n_fc2 * B_FC2) / n_all)
 out = {}
 for tag, pat in TAGS.items():
     f = [(v, n) for k, (v, n) in fetch.items() if pat in k]
@@ -35,5 +42,7 @@ for tag, pat in TAGS.items():
         if tag in ALGO:
             out[tag]["algorithmic_bytes_per_launch"] = ALGO[tag]
             out[tag]["traffic_over_algorithmic"] = round(out[tag]["bytes_per_launch"] / ALGO[tag], 2)
+        if tag == "vit.proj+fc2" and n_all > n_fc2 > 0:
+            out[tag]["launch_mix"] = {"proj": n_all - n_fc2, "fc2": n_fc2}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -36,8 +36,15 @@ python tools/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collecti
                             "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" > /dev/null
 head -1 "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_csv_header.txt"
 # encode calls in the single-stream trace: 3 warm-up + 10 timed + 3 clock-probe steps
-python tools/kernel_table.py "$OUT/kernel_stats_single_stream.csv" "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" 16 \
+python tools/kernel_table.py "$OUT/kernel_stats_single_stream.csv" "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" 16 "$OUT/bench.json" \
     > "$OUT/per_kernel_table.md" 2> "$OUT/per_kernel_table.err"
+# 5. the text tower (SURVEY.md 8d asks prompts/s beside tiles/s): config 3's 64 x 256 prompt bank, at the trimmed and at the padded length
+cd /tmp
+for t in 1 0; do
+  rocprofv3 --kernel-trace --stats -d /tmp/kt_text$t --output-format csv -- python "$REPO/tools/text_profile.py" --trim $t > "$OUT/text_trim$t.txt" 2> "$OUT/kt_text$t.log"
+  cp "$(find /tmp/kt_text$t -name '*kernel_stats.csv' | head -1)" "$OUT/text_kernel_stats_trim$t.csv"
+done
+cd "$REPO"
 unset KEEP_CALIBRATE
 python tools/clock_check.py > "$OUT/clock_under_load.txt" 2>&1
 cat "$OUT/per_kernel_table.md"; cat "$OUT/pmc_csv_header.txt"
