@@ -105,6 +105,7 @@ struct keep_handle {
                                  // q / k / v still stored as hi + lo planes, attention still a split product.  Measured (round 3): +0.9 % at equal settings,
                                  // but block 0's qkv is where the error budget is tightest (the 3 % of the rounding variance the fp4 terms leave is
                                  // amplified by all 24 blocks): calibrate() then needs 10 compensated MLP blocks instead of 6 -- a net loss.  Off.
+    int comp_qkv_from = 1 << 20; // the same for the split-attention blocks with index >= this only (block 0 keeps its three-pass qkv)
     // keep_classify: tiles whose top-2 cosine margin is below this are re-encoded in KEEP_PREC_STRICT before their label is taken.
     // Default = 2 x the north-star tolerance (both cosines of a pair can move by 1e-4 in opposite directions) + 25 %.
     float label_margin = 2.5e-4f;
@@ -168,7 +169,7 @@ struct keep_handle {
     bool txt_must_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
     bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
     bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 128 == 0)
-    bool any_comp() const { return precision == KEEP_PREC_COMP && vit_has_q && (comp_mlp_blocks > 0 || (comp_full_blocks > 0 && comp_qkv)); }
+    bool any_comp() const { return precision == KEEP_PREC_COMP && vit_has_q && (comp_mlp_blocks > 0 || (comp_full_blocks > 0 && (comp_qkv || comp_qkv_from < comp_full_blocks))); }
 
     bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && ((prof_mask >> tag) & 1ull)); }
     void prof_add_flops(int tag, double f) { if (prof_on(tag)) prof_flops[tag] += f; }
@@ -418,7 +419,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
 #endif
     // qkv of a split-attention block in the compensated mode: fp16 pass + MX-fp4 correction terms instead of three fp16 passes (lanes
     // large enough for the 256x256 kernel; LayerNorm-1 then writes the fp4 planes of its output instead of the lo plane)
-    const bool qkv_q = sp && h->precision == KEEP_PREC_COMP && i >= h->strict_blocks && h->comp_qkv && Bc >= h->comp_min_tiles && b.qkv->q && ws.xn_q && !L.xn_ready;
+    const bool qkv_q = sp && h->precision == KEEP_PREC_COMP && i >= h->strict_blocks && (h->comp_qkv || i >= h->comp_qkv_from) && Bc >= h->comp_min_tiles && b.qkv->q && ws.xn_q && !L.xn_ready;
     LnParams ln{};
     ln.tune = &h->tune;
     ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
@@ -1132,6 +1133,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
     else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
     else if (n == "comp_qkv") { h->comp_qkv = v ? 1 : 0; }
+    else if (n == "comp_qkv_from") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_qkv_from < 0"); h->comp_qkv_from = v; }
     else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
     else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
@@ -1175,6 +1177,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "comp_mlp_blocks") return h->comp_mlp_blocks;
     if (n == "comp_min_tiles") return h->comp_min_tiles;
     if (n == "comp_qkv") return h->comp_qkv;
+    if (n == "comp_qkv_from") return h->comp_qkv_from;
     if (n == "max_tiles") return h->max_tiles;
     if (n == "max_prompts") return h->max_prompts;
     if (n == "gemm_impl") return t.gemm_impl;
