@@ -101,6 +101,7 @@ int keep_bert_layers(keep_handle* h);
  *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
  *   "comp_qkv"         KEEP_PREC_COMP: 1 = the qkv GEMM of the split-attention blocks as a compensated product instead of a split one
  *                     (default 0: +0.9 % at equal settings, but calibrate() then needs more compensated MLP blocks -- a net loss)
+ *   "comp_qkv_from"    the same for the split-attention blocks with index >= n only (default: none; round 4: 2 / 6 with n = 1 misses the rms target 1 / 8 meets)
  *   "label_margin"     keep_classify: cosine margin below which a tile's label is re-derived in KEEP_PREC_STRICT (default 2.5e-4)
  *   "fused_screening"  keep_prompt_scores with C in {2, 4}: 1 (default) one compensated GEMM with the top-2 score taken in the
  *                     accumulator registers (no logits in HBM) | 2 the same with three fp16 passes | 0 chunked fp32 GEMM + reduction
@@ -186,6 +187,8 @@ int keep_similarity(keep_handle* h, const float* img, const float* txt, int64_t 
  *   then re-encodes ONLY the tiles whose top-2 margin (in cosine units, i.e. / scale) is below `margin` in KEEP_PREC_STRICT (split
  *   products, ~5e-7) and takes those rows again.  margin < 0: the handle's "label_margin" option (default 2.5e-4 = 2 x tolerance + 25 %);
  *   margin == 0: no second look.  One host synchronisation of `stream` (the number of flagged tiles).
+ *   The labels are those of the split-product arithmetic provided the first pass is within margin / 2 of it: true in KEEP_PREC_COMP (<= 1e-4 against
+ *   2.5e-4); in KEEP_PREC_FP16 (~2e-4) pass a margin of at least twice that mode's error.
  *   pixels / pix_dtype / B as keep_encode_image (16-byte aligned); txt fp32 [P,D] L2-normalised text features (keep_encode_text);
  *   feats_out fp32 [B,D] or NULL; sim_out fp32 [B,P] or NULL; labels_out int32 [B] (first maximum wins, as torch.argmax);
  *   n_rechecked (HOST pointer or NULL): how many tiles were encoded twice. */
