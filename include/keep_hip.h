@@ -124,7 +124,8 @@ int keep_bert_layers(keep_handle* h);
  *                     tile per workgroup.  Bit-identical results either way.
  *   "sgemv_m"         same for the few-row fp32 kernel of the projection head / pooler / similarity (default 16)
  *   "ln_impl"         1 (default) LayerNorm with LDS-transposed K-blocked stores | 0 per-row stores
- *   "attn_waves"      wavefronts per attention workgroup, 8 (default) | 4
+ *   "attn_waves"      16 (default): image-tower attention of >= 512 (image, head) pairs on the persistent double-buffered kernel (bit-identical
+ *                     to 8, the K / V staging of the next pair runs under the current one's compute), 8 waves per workgroup elsewhere | 8 | 4
  *   "lane0_permille", "lane_skew"   experiments with the two-lane schedule (defaults 500 / 0 measured best)
  *   "gemm_ablate", "gemm_dbg", "dbg_skip_ln"   timing diagnostics (results are wrong when ablating): -DKEEP_DIAGNOSTICS builds only
  */

@@ -322,6 +322,199 @@ void attention_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent variant for the image tower (197 tokens = 13 query tiles, no key mask, single fp16 pass): one 16-wave workgroup per CU walks
+// the (image, head) pairs with stride gridDim.x.  Waves 0..12 own ONE query tile each (the 13 tiles of a head over 8 waves left three
+// waves with one tile and five with two); waves 13..15 issue the LDS-DMA that stages the NEXT pair's K and V into the other half of a
+// double buffer while the thirteen compute, so that staging (1.1 of the 2.6 ms per step of the one-pair-per-workgroup kernel) runs under
+// the compute instead of in front of it, and the computing waves issue no DMA at all.  Same arithmetic, same summation order per tile as
+// attention_kernel<13, false, 8>: bit-identical results.
+template <int NT>
+__global__ __launch_bounds__(1024, 4)
+void attention_pers_kernel(AttnParams p) {
+    constexpr int NW = 16, NCW = NT, NLW = NW - NCW;
+    static_assert(NLW >= 1, "needs at least one loader wave");
+    constexpr int NKP = NT * 16;
+    constexpr int NU = (NT + 1) / 2;
+    constexpr int BUF_ELEMS = NKP * HD + att_kp2(NT) * HD;           // K image + V image of one (image, head)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f16* sBuf = reinterpret_cast<f16*>(smem);
+    float* sBias = reinterpret_cast<float*>(sBuf + 2 * BUF_ELEMS);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntok = p.ntok, heads = p.heads;
+    const int D = heads * HD, D3 = 3 * D;
+    const int items = p.batch * heads;
+    int item = blockIdx.x;
+    if (item >= items) return;
+
+    {   // first pair: every wave stages
+        const int b = item / heads, h = item - b * heads;
+        stage_kv<NT, NW * 64>(p.qkv_hi + (int64_t)b * ntok * D3, ntok, D3, D + h * HD, 2 * D + h * HD, sBuf, sBuf + NKP * HD, tid, wave);
+    }
+    for (int k = tid; k < NKP; k += NW * 64) sBias[k] = k >= ntok ? -INFINITY : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int qi = lane & 15, g = lane >> 4;
+    const float sc2 = p.scale * 1.4426950408889634f;
+    const bool o_blk = p.out_kt > 0;
+    const unsigned o_sa = o_blk ? (unsigned)p.out_kt * 8192u : 256u * (unsigned)D, o_sb = o_blk ? 32u : (unsigned)D;
+    const unsigned o_ga = o_blk ? 8192u : 32u;
+    int qrow = wave * 16 + qi;                                     // this lane's query (compute waves)
+    const bool q_valid = qrow < ntok;
+    qrow = q_valid ? qrow : ntok - 1;
+    f16x8 qn[2];
+    auto load_q = [&](int it) {
+        const int b = it / heads, h = it - b * heads;
+        const f16* base = p.qkv_hi + (int64_t)b * ntok * D3;
+        const unsigned qo = (unsigned)qrow * (unsigned)D3 + (unsigned)(h * HD + g * 8);
+        qn[0] = *reinterpret_cast<const f16x8*>(base + qo);
+        qn[1] = *reinterpret_cast<const f16x8*>(base + (qo + 32));
+    };
+    if (wave < NCW) load_q(item);
+    asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));
+
+    for (int cur = 0;; cur ^= 1) {
+        const int nxt = item + (int)gridDim.x;
+        const bool more = nxt < items;
+        const f16* sK = sBuf + cur * BUF_ELEMS;
+        const f16* sVt = sK + NKP * HD;
+        if (wave >= NCW) {
+            if (more) {
+                const int b = nxt / heads, h = nxt - b * heads;
+                f16* dK = sBuf + (cur ^ 1) * BUF_ELEMS;
+                stage_kv<NT, NLW * 64>(p.qkv_hi + (int64_t)b * ntok * D3, ntok, D3, D + h * HD, 2 * D + h * HD, dK, dK + NKP * HD, tid - NCW * 64, wave - NCW);
+            }
+        } else {
+            const int b = item / heads, h = item - b * heads;
+            f16x8 qf[2] = {qn[0], qn[1]};
+            if (more) load_q(nxt);
+#define KEEP_MEM_BARRIER() asm volatile("" ::: "memory")
+            KEEP_MEM_BARRIER();
+            f32x4 s[NT];
+            f16x8 kf[2][2];
+            auto load_k = [&](int kt, int slot) {
+                const int row = kt * 16 + qi;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    kf[slot][ks] = *reinterpret_cast<const f16x8*>(sK + row * HD + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3));
+            };
+            load_k(0, 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                if (kt + 1 < NT) load_k(kt + 1, (kt + 1) & 1);
+                KEEP_MEM_BARRIER();
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + kt * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][r] = s[kt][r] * sc2 + bias[r];
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+                if ((kt & 3) == 3) KEEP_MEM_BARRIER();
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+            f16x8 ph[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                float a0[4], a1[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a0[r] = __builtin_amdgcn_exp2f(s[2 * u][r] - mx);
+                    a1[r] = (2 * u + 1 < NT) ? __builtin_amdgcn_exp2f(s[(2 * u + 1 < NT) ? 2 * u + 1 : 0][r] - mx) : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += a0[r];
+                if (2 * u + 1 < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum += a1[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ph[u][r] = (f16)a0[r]; ph[u][4 + r] = (f16)a1[r]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f16x4 va[2][4][2];
+            auto load_v = [&](int u, int slot) {
+                const int vrow = 32 * u + 4 * g + (qi >> 2);
+                const int vsw = (2 * g + (qi >> 3)) & 3;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int voff = vrow * HD + ((dt ^ vsw) << 4) + ((qi & 3) << 2);
+                    va[slot][dt][0] = tr_read4(sVt + voff);
+                    va[slot][dt][1] = tr_read4(sVt + voff + 16 * HD);
+                }
+            };
+            KEEP_MEM_BARRIER();
+            load_v(0, 0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u + 1 < NU) load_v(u + 1, (u + 1) & 1);
+                KEEP_MEM_BARRIER();
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f16x4 v0 = va[u & 1][dt][0], v1 = va[u & 1][dt][1];
+                    const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph[u], o[dt], 0, 0, 0);
+                }
+            }
+#undef KEEP_MEM_BARRIER
+            asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));          // the prefetched Q is waited for here, before this tile's stores go out
+            if (q_valid) {
+                const int mrow = b * ntok + qrow;
+                const unsigned o_g0 = (o_blk ? (unsigned)(h * 2) * 8192u : (unsigned)(h * HD)) + (unsigned)(g * 4);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    f16x4 oh;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f16 hh, ll; split_f16(o[dt][r] * inv, hh, ll); oh[r] = hh; }
+                    const unsigned oo = (unsigned)(mrow >> 8) * o_sa + (unsigned)(mrow & 255) * o_sb + o_g0 + (unsigned)(dt >> 1) * o_ga + (unsigned)(dt & 1) * 16u;
+                    *reinterpret_cast<f16x4*>(p.out_hi + oo) = oh;
+                }
+            }
+        }
+        if (!more) break;
+        // the loader waves' DMA must have landed before anyone reads the other buffer; nobody may still read this one when the next
+        // staging (into it, one iteration on) begins: one barrier does both
+        if (wave >= NCW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        item = nxt;
+    }
+}
+
+template <int NT>
+int launch_pers(const AttnParams& p, hipStream_t s) {
+    constexpr size_t bytes = (size_t)2 * ((size_t)NT * 16 * HD + (size_t)att_kp2(NT) * HD) * 2 + (size_t)NT * 16 * 4;
+    static unsigned long long done = 0;
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev >= 64) return -2;
+    if (!((done >> dev) & 1ull)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pers_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -2;
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        done |= 1ull << dev;
+    }
+    const int items = p.batch * p.heads;
+    hipLaunchKernelGGL((attention_pers_kernel<NT>), dim3(items < cus[dev] ? items : cus[dev]), dim3(1024), bytes, s, p);
+    return 0;
+}
+
 template <int NT, bool SPLIT, int NW>
 int launch_one(const AttnParams& p, hipStream_t s) {
     constexpr size_t bytes = att_lds_bytes(NT, SPLIT);
@@ -361,8 +554,10 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     }
     if (nt <= 4) return launch_one<4, false, 4>(p, s);
     if (nt <= 8) return launch_one<8, false, 4>(p, s);
-    if (nt <= 13) return g_attn_waves == 8 ? launch_one<13, false, 8>(p, s) : launch_one<13, false, 4>(p, s);
-    if (nt <= 16) return g_attn_waves == 8 ? launch_one<16, false, 8>(p, s) : launch_one<16, false, 4>(p, s);
+    // image tower at full width: the persistent double-buffered kernel (attn_waves = 16) when there are more (image, head) pairs than CUs can hold at once
+    if (nt == 13 && g_attn_waves == 16 && !p.mask && p.q_rows <= 0 && p.batch * p.heads >= 512 && launch_pers<13>(p, s) == 0) return 0;
+    if (nt <= 13) return g_attn_waves == 4 ? launch_one<13, false, 4>(p, s) : launch_one<13, false, 8>(p, s);
+    if (nt <= 16) return g_attn_waves == 4 ? launch_one<16, false, 4>(p, s) : launch_one<16, false, 8>(p, s);
     if (nt <= 32) return launch_one<32, false, 4>(p, s);
     return -1;
 }

@@ -72,7 +72,8 @@ struct KeepTune {
     int gemm_splitk_tiles = 64;  // a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never)
     int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
     int ln_impl = 1;             // 1: LDS-transposed blk stores; 0: per-row stores
-    int attn_waves = 8;          // wavefronts per attention workgroup for 13/16-tile sequences (4 or 8)
+    int attn_waves = 16;         // 16: image-tower calls with >= 512 (image, head) pairs take the persistent double-buffered kernel (13 compute + 3 loader waves),
+                                 //     everything else 8 waves per workgroup; 8 / 4: one (image, head) pair per workgroup of that many waves
     int gemm_persistent = 1;     // 1: plain 256x256 GEMMs with more tiles than CUs run as one workgroup per CU walking the tile list, the next tile's
                                  //    first three K steps prefetched under the epilogue (0: one tile per workgroup; n > 1: n workgroups, experiments)
     int gemm_ablate = 0;         // diagnostics (KEEP_DIAGNOSTICS builds only)

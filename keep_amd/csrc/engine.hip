@@ -1148,7 +1148,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
     else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); t.ln_impl = v; }
-    else if (n == "attn_waves") { if (v != 4 && v != 8) return h->fail(KEEP_EINVAL, "attn_waves must be 4 or 8"); t.attn_waves = v; }
+    else if (n == "attn_waves") { if (v != 4 && v != 8 && v != 16) return h->fail(KEEP_EINVAL, "attn_waves must be 4, 8 or 16 (16: persistent double-buffered kernel for the image tower)"); t.attn_waves = v; }
     else if (n == "gemm_impl") {
         bool ok = v == 0 || v == 128 || v == 256;
         if (!ok) return h->fail(KEEP_EINVAL, "gemm_impl %d (0, 128, 256)", v);

@@ -257,6 +257,24 @@ def test_attention_unmasked(ops, B, T, heads, split):
     assert (out - ref).abs().max() < tol
 
 
+@pytest.mark.parametrize("B", [33, 40, 64])
+def test_persistent_attention_is_bit_identical(B):
+    """Image-tower attention (197 tokens, 16 heads, no mask) with >= 512 (image, head) pairs runs on the persistent kernel: one 16-wave workgroup
+    per CU walks the pairs, 13 waves compute one query tile each while 3 waves stage the next pair's K / V into the other half of a double buffer.
+    Same arithmetic and summation order per tile as the one-pair-per-workgroup kernel: equal bit for bit, also when the pairs do not divide
+    evenly over the CUs (33 x 16 = 528 pairs on 256 workgroups) -- and equal to the fp64 reference within the fp16 budget."""
+    from keep_amd.ops import Ops
+    T, heads = 197, 16
+    qkv = rand(B * T, 3 * heads * 64, seed=24, std=1.5)
+    outs = {}
+    for waves in (8, 16):
+        o = Ops("cuda:0")
+        o.set_option("attn_waves", waves)
+        outs[waves] = o.attention(qkv, B, T, heads, None, False)
+    assert torch.equal(outs[8], outs[16])
+    assert (outs[16][: 2 * T].cpu().double() - attn_ref(qkv[: 2 * T], 2, T, heads, None, True)).abs().max() < 4e-3
+
+
 @pytest.mark.parametrize("T", [256, 40])
 @pytest.mark.parametrize("split", [False, True])
 def test_attention_key_padding_mask(ops, T, split):

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--precision", default="comp")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--breakdown", action="store_true", help="also print the per-operator times of a single-stream pass")
     args = ap.parse_args()
     if args.compare:
         a, b = (torch.load(p) for p in args.compare)
@@ -47,6 +48,16 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(f"{os.path.basename(_lib.LIB_PATH)}: {args.tiles / dt:.1f} tiles/s, {dt * 1e3:.3f} ms/step")
+    if args.breakdown:
+        from keep_amd import PROFILE_TAGS
+        m.set_option("streams", 1)
+        m.profile_enable(None)
+        m.profile_reset()
+        for _ in range(3):
+            m.encode_image(x)
+        torch.cuda.synchronize()
+        print("   single stream, ms per step:", {t: round(m.profile_read(t)[0] / 3, 3) for t in PROFILE_TAGS if m.profile_read(t)[1]})
+        m.profile_disable()
     if args.out:
         torch.save(f.cpu(), args.out)
 
