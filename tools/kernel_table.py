@@ -25,6 +25,7 @@ KERNELS = [
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, false>", "qkv GEMM, split product (block 0: 3 fp16 passes)", G(3072, 1024), None, "mfma"),
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, false>", "proj GEMM, split product (block 0)", G(1024, 1024), None, "mfma"),
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 3, false, false>", "patch-embed GEMM, split product", 2.0 * 256 * 196 * 768 * 1024, None, "mfma"),
+    (r"attention_pers_kernel<13>", "attention (197 tokens, 16 heads; persistent, next pair's K / V staged under the compute)", 4.0 * 256 * 16 * 197 * 197 * 64, 2.0 * M * 4096, "mfma"),
     (r"attention_kernel<13, false, 8>", "attention (197 tokens, 16 heads)", 4.0 * 256 * 16 * 197 * 197 * 64, 2.0 * M * 4096, "mfma"),
     (r"attention_kernel<13, true, 4>", "attention, split product (block 0)", 4.0 * 256 * 16 * 197 * 197 * 64, 4.0 * M * 4096, "mfma"),
     (r"layernorm_blk_kernel<4, 8>", "LayerNorm (fp32 in, fp16 K-blocked out [+ lo / fp4 planes])", None, 6.0 * M * 1024, "hbm"),

@@ -20,7 +20,7 @@ write = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
 # template arguments: <BN, WM, WN, NSTAGE, EPI, COMP, PERS>
 TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>",
         "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, true>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>",
-        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "vit.attn": "attention_kernel<13, false, 8>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
+        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "vit.attn": "attention_pers_kernel<13>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
 # algorithmic bytes per launch of one 128-tile lane (M = 25 216 rows): operands read once + outputs written once (+ fp32 residual read-modify-write)
 M = 128 * 197
 ALGO = {"vit.fc1": 2 * (M * 1024 + 4096 * 1024) + 2 * M * 4096, "vit.qkv": 2 * (M * 1024 + 3072 * 1024) + 2 * M * 3072,

@@ -35,6 +35,8 @@ sha256sum keep_amd/libkeep_hip.so | cut -c1-16 > "$OUT/lib_sha16.txt"
 python tools/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" \
                             "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" > /dev/null
 head -1 "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_csv_header.txt"
+# the raw single-stream counter CSV travels back too (a few MB), so that tools/kernel_table.py can be re-run off the box
+gzip -c "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_mfma_single_stream_counter_collection.csv.gz"
 # encode calls in the single-stream trace: 3 warm-up + 10 timed + 3 clock-probe steps
 python tools/kernel_table.py "$OUT/kernel_stats_single_stream.csv" "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" 16 "$OUT/bench.json" \
     > "$OUT/per_kernel_table.md" 2> "$OUT/per_kernel_table.err"
