@@ -116,6 +116,10 @@ def cpu_baseline(sd, tiles: int = 8, iters: int = 40, min_seconds: float = 10.0)
                       f"synthetic weights; CPU: {cpu_model_name()}"}
 
 
+def tiles_per_s_for_ceiling(world, B, steps, elapsed) -> float:
+    return B * steps / elapsed           # per GPU
+
+
 def lib_sha16() -> str:
     import hashlib
     from keep_amd import _lib
@@ -489,6 +493,17 @@ def main():
         model.profile_disable()
         model.set_option("streams", streams_was)
 
+    # context for the roofline fractions: what the matrix pipes ALONE sustain on this box at the socket's power cap, no memory traffic (keep_mfma_probe)
+    pipe_ceiling = None
+    if rank == 0 and not args.no_breakdown:
+        rnd = model.mfma_ceiling()
+        zer = model.mfma_ceiling(torch.zeros(1024, dtype=torch.float16, device=dev))
+        pipe_ceiling = {"random_N01_fp16_operands_TFLOPs": round(rnd, 1), "frac_of_peak": round(rnd / PEAK_F16_TFLOPS, 4),
+                        "all_zero_operands_TFLOPs": round(zer, 1),
+                        "note": "v_mfma_f32_32x32x16_f16 back to back on every SIMD, operands in registers, no memory access: with high-entropy operands the power cap "
+                                "holds the pipes at ~1.6 GHz, so ~0.63 of the nominal peak is what the silicon offers fp16 GEMM work on real data; the fractions above stay "
+                                "quoted against the nominal peak",
+                        "end_to_end_frac_of_this_ceiling": round(tiles_per_s_for_ceiling(world, B, args.steps, elapsed) * vit_flops_per_tile() / (rnd * 1e12), 4) if rnd > 0 else None}
     c3 = c4 = c5 = parity = None
     if want_configs:
         log("config 3 (4096 tiles x 64 prompts, parity vs the oracle fixture) ...")
@@ -546,6 +561,8 @@ def main():
                     "note": "achieved / frac = ALGORITHMIC FLOPs (2*M*N*K per launch; correction passes are never counted) / summed launch durations; "
                             "frac_end_to_end = tiles/s x 123.11 GFLOP / peak over the whole encoder (the figure the driver can check against its own clock); "
                             "peak = 256 CU x 4096 FLOP/clk x 2.4 GHz dense fp16"}
+        if pipe_ceiling is not None:
+            roofline["matrix_pipe_ceiling_measured"] = pipe_ceiling
         if clock is not None:
             roofline["clock"] = clock
             roofline["frac_of_peak_at_effective_clock"] = round(frac_e2e * 2400.0 / clock["effective_shader_MHz_median"], 4)

@@ -269,6 +269,12 @@ int keep_op_l2norm(keep_handle* h, float* x, int64_t rows, int64_t D, void* stre
  * (two int64 on the device): effective shader clock = cycles / ticks * 100 MHz.  Launched on a side stream next to a running workload it
  * reads the clock the part actually sustains under that load (bench.py records it; the MFMA peak is quoted at 2.4 GHz). */
 int keep_clock_probe(keep_handle* h, int spin_us, long long* device_out2, void* stream);
+/* measurement aid: what the matrix pipes alone deliver on this part with the caller's operand values.  One 8-wave workgroup per CU; every wave loads
+ * 6 fp16 fragments (6 x 16 B per lane: operands_f16 holds CUs x 512 x 48 fp16 values) and issues `iters` x 8 independent v_mfma_f32_32x32x16_f16 with no
+ * memory access in the loop; sink (fp32, CUs x 512) receives one value per lane.  *flops_out (host) = the FLOPs of the launch; time it with events on
+ * `stream`.  With N(0, 1)-like operands the socket's power cap holds the pipes at ≈1.6 GHz: ≈1 590 TFLOP/s = 0.63 of the nominal dense peak that the roofline
+ * fractions are quoted against; with zeros 2 480 (profiles/r04_mfma_power_ceiling.txt).  bench.py reports it as context next to `roofline`. */
+int keep_mfma_probe(keep_handle* h, const void* operands_f16, float* sink, int iters, double* flops_out, void* stream);
 /* diagnostics: with option "gemm_dbg"=1 every GEMM launch records, per workgroup, four shader-clock
  * stamps [start, first K tile landed, main loop end, end]; this copies them to host memory. */
 int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes);

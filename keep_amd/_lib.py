@@ -57,6 +57,7 @@ SIGNATURES = {
     "keep_op_sgemm": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _vp, _vp]),
     "keep_op_l2norm": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "keep_clock_probe": (_i32, [_vp, _i32, _vp, _vp]),
+    "keep_mfma_probe": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(C.c_double), _vp]),
     "keep_debug_read": (_i32, [_vp, _vp, _i64]),
 }
 

@@ -1677,6 +1677,35 @@ int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int
     return check_launch(h, "op_attention");
 }
 
+// Matrix-pipe ceiling probe (keep_mfma_probe): no memory traffic inside the loop; every wave holds 2 A and 4 B fragments of the caller's data in registers and
+// issues 8 independent v_mfma_f32_32x32x16_f16 per iteration (all (i, j) pairs: the pipe's inputs change with every instruction); one 8-wave workgroup per CU,
+// two waves per SIMD, as the GEMM kernels run.
+__global__ __launch_bounds__(512, 2) void mfma_probe_kernel(const f16x8* __restrict__ src, float* __restrict__ sink, int iters) {
+    f16x8 a[2], b[4];
+    const int t = blockIdx.x * 512 + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = src[(size_t)t * 6 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = src[(size_t)t * 6 + 2 + i];
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i * 4 + j], 0, 0, 0);
+    }
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += acc[i][r];
+    sink[t] = v;
+}
+
 int keep_op_layernorm(keep_handle* h, const float* x, const float* add, const float* gamma, const float* beta, int64_t rows,
                       int64_t D, float eps, float* out, void* stream) {
     if (!h || !x || !gamma || !beta || !out || rows < 1) return h ? h->fail(KEEP_EINVAL, "bad layernorm arguments") : KEEP_EINVAL;
@@ -1707,6 +1736,16 @@ int keep_debug_read(keep_handle* h, void* host_dst, int64_t bytes) {
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(host_dst, h->tune.dbg, bytes, hipMemcpyDeviceToHost));
     return KEEP_OK;
+}
+
+int keep_mfma_probe(keep_handle* h, const void* operands_f16, float* sink, int iters, double* flops_out, void* stream) {
+    if (!h || !operands_f16 || !sink || iters < 1 || iters > (1 << 24)) return h ? h->fail(KEEP_EINVAL, "bad mfma_probe arguments") : KEEP_EINVAL;
+    KEEP_ON_DEVICE(h);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus < 1) cus = 256;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, (hipStream_t)stream, (const f16x8*)operands_f16, sink, iters);
+    if (flops_out) *flops_out = (double)cus * 8.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+    return check_launch(h, "mfma_probe");
 }
 
 int keep_clock_probe(keep_handle* h, int spin_us, long long* device_out2, void* stream) {

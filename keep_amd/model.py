@@ -669,6 +669,32 @@ class KEEPModel:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream(self._device)
         _lib.check(self._handle, _lib.load().keep_clock_probe(self._handle, int(spin_us), _ptr(out), st), "clock_probe")
 
+    def mfma_ceiling(self, operands: Optional[torch.Tensor] = None, iters: int = 100_000, reps: int = 3) -> float:
+        """TFLOP/s the matrix pipes alone sustain on this GPU with ``operands`` (fp16 values; default seeded N(0, 1)) and no memory traffic
+        (``keep_mfma_probe``): the ceiling the socket's power cap leaves for high-entropy fp16 MFMA work -- context for roofline fractions that
+        are quoted against the nominal 2.4 GHz peak."""
+        self._ready_device()
+        dev = self._device
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        n = cus * 512 * 48
+        if operands is None:
+            g = torch.Generator(device=dev).manual_seed(7)
+            operands = torch.randn(n, device=dev, generator=g, dtype=torch.float32).to(torch.float16)
+        src = operands.to(dev, torch.float16).contiguous().flatten()
+        if src.numel() < n:
+            src = src.repeat(-(-n // src.numel()))[:n].contiguous()
+        sink = torch.empty(cus * 512, dtype=torch.float32, device=dev)
+        fl = C.c_double(0)
+        best = 0.0
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream(dev))
+            _lib.check(self._handle, _lib.load().keep_mfma_probe(self._handle, _ptr(src), _ptr(sink), int(iters), C.byref(fl), _stream(dev)), "mfma_probe")
+            b.record(torch.cuda.current_stream(dev))
+            b.synchronize()
+            best = max(best, fl.value / (a.elapsed_time(b) * 1e-3) / 1e12)
+        return best
+
     # ------------------------------------------------------------------ profiling passthrough
     def profile_enable(self, tag: Optional[str] = None):
         self._ready_device()

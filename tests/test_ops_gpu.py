@@ -342,3 +342,18 @@ def test_l2norm(ops):
     x[5] = 0
     ref = torch.nn.functional.normalize(x.cpu(), dim=-1)
     assert (ops.l2norm_(x).cpu() - ref).abs().max() < 1e-6
+
+
+def test_matrix_pipe_ceiling_probe():
+    """keep_mfma_probe (measurement aid, as keep_clock_probe): MFMAs back to back on every SIMD with no memory traffic.  The pipes reach the nominal
+    dense peak only with operands that do not toggle the multipliers; with N(0, 1) operands the socket's power cap holds them far below it -- the
+    context bench.py prints next to its roofline fractions (profiles/r04_mfma_power_ceiling.txt: 1 590 vs 2 480 TFLOP/s)."""
+    from keep_amd import KEEPModel
+    m = KEEPModel()
+    m._ready_device()
+    rnd = m.mfma_ceiling(iters=20_000, reps=2)
+    zer = m.mfma_ceiling(torch.zeros(4096, dtype=torch.float16, device="cuda"), iters=20_000, reps=2)
+    print(f"matrix-pipe ceiling: random operands {rnd:.0f} TFLOP/s, zeros {zer:.0f} TFLOP/s")
+    assert 500.0 < rnd < 2600.0 and 1500.0 < zer < 2600.0 and zer > rnd
+    with pytest.raises(ValueError):
+        m.mfma_ceiling(iters=0)
