@@ -84,7 +84,9 @@ class KEEPModel:
         # out-of-range token ids raise IndexError, as nn.Embedding does.  True: checked before encode_text returns (one host
         # synchronisation per call); "lazy": the flag is copied back asynchronously and the error is raised by the NEXT engine call
         # or by check_errors() -- no synchronisation, which is also how the reference's CUDA path reports it (device-side assert);
-        # False: never checked.  The reference's WSI scripts make thousands of one-prompt calls, so the default is "lazy".
+        # False: never checked -- and that includes the non-finite-feature bit (an activation beyond the fp16 range of the engine's stores reaches the
+        # output as NaN; with False nothing raises, the caller sees the NaNs).  The reference's WSI scripts make thousands of one-prompt calls, so the
+        # default is "lazy".
         self.check_token_ids = "lazy"
         self._pending_token_checks = []   # [(pinned int32 flag, event)] in issue order; the device flag is sticky, so none can be lost
         self._flag_pool = []              # pinned buffers are recycled only after their copy has landed
