@@ -38,13 +38,14 @@ rccl_env()        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: what RCCL's multi-
 
 from keep_amd import KEEPModel, PROFILE_TAGS, vit_flops_per_tile          # noqa: E402
 from keep_amd.config import KEEPShape                                      # noqa: E402
+from keep_amd.model import plan_string                                    # noqa: E402
 from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles    # noqa: E402
 
 PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense
 PEAK_HBM_GBS = 8000.0
 # The kernel that takes the largest share of a step: gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,false,true> -- the persistent 256x256 GEMM with the
 # LayerScale + fp32 residual read-modify-write epilogue, launched for proj ([B*197,1024] x [1024,1024]) and fc2 ([B*197,4096] x [4096,1024]) of every
-# block that runs single fp16 passes (26-27 % of the step; profiles/r03_per_kernel_table.md).  The engine times those launches under these two tags.
+# block that runs single fp16 passes (the largest share of the step: profiles/r05_per_kernel_table.md).  The engine times those launches under these two tags.
 DOMINANT_TAGS = ("vit.proj", "vit.fc2")
 DOMINANT_KERNEL = "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,false,true> (persistent; vit.proj + vit.fc2 launches of the plain blocks)"
 BERT_FLOPS_PER_PROMPT_256 = 45_903_642_624
@@ -222,96 +223,133 @@ def rcc_shaped_bank(txt, K=1782, C=4, seed=11):
 
 
 def diff_stats(d):
-    from keep_amd.model import expected_max_sigmas
+    from keep_amd.model import max_sigmas_gumbel, max_sigmas_quantile
     mx, rms = float(d.abs().max()), float(d.double().pow(2).mean().sqrt())
+    a, b = max_sigmas_gumbel(d.numel())
     return {"max_abs": float(f"{mx:.3e}"), "rms": float(f"{rms:.3e}"), "max_over_rms": round(mx / max(rms, 1e-30), 2), "n": int(d.numel()),
-            "gaussian_expectation_of_max_over_rms": round(expected_max_sigmas(d.numel()), 2), "over_1e-4": int((d.abs() > 1e-4).sum())}
+            "gaussian_max_over_rms": {"location": round(b, 2), "mean": round(b + 0.5772 / a, 2), "quantile_0.99": round(max_sigmas_quantile(d.numel(), 0.99), 2)},
+            "over_1e-4": int((d.abs() > 1e-4).sum())}
 
 
-def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, topn: int = 50, settings=None):
-    """BASELINE config 4 at its stated size on one GPU: a 100 000-tile synthetic slide (tiles generated on the device, 256 per batch) encoded in the
-    model's current 'comp' setting and in 'strict' (split products: pinned to 6.4e-7 of the fp32 oracle on config 3), then the reference's subtyping /
-    detection flow on both feature sets.  Reports every cosine difference against a 64-prompt bank (N x 64) and against the `distinct` prompt strings a
-    K x 4 classifier bank of the RCC shape is built from (N x 264 distinct cosines = everything the N x 7128 screening logits can contain), the
-    screening scores, the selected ensemble, the slide label and the tumour ratio.  `settings`: extra (comp_full_blocks, comp_mlp_blocks) pairs to
-    measure the same way (tools/c4_parity.py); the model's own setting is always measured and restored."""
+C4_SEEDS = (1000, 2000, 3000, 4000, 5000)        # tile seeds of the config-4 leg: each is a different 100 000-tile synthetic slide
+
+
+def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, topn: int = 50, settings=None, seeds=C4_SEEDS):
+    """BASELINE config 4 at its stated size on one GPU, on SEVERAL synthetic slides (`seeds`): n tiles (generated on the device, 256 per batch)
+    encoded in the model's current 'comp' plan and in 'strict' (split products: pinned to 6.4e-7 of the fp32 oracle on config 3).  Per slide: every
+    cosine difference against a 64-prompt bank (n x 64) and against the `distinct` prompt strings a K x 4 classifier bank of the RCC shape is built
+    from (n x 264 distinct cosines = everything the n x 7128 screening logits can contain) -- text features of the comp side encoded in the
+    benched mode, of the reference side in 'strict'.  On the first slide also the reference's subtyping / detection flow on both feature sets:
+    screening scores, the selected ensemble, the slide label, the tumour ratio.  `settings`: extra plans to measure on the first slide the same way
+    ((comp_full_blocks, comp_mlp_blocks) pairs or per-block plans; tools/c4_parity.py); the model's own plan is always measured and restored."""
     from keep_amd import wsi
+    from keep_amd.model import plan_prefix, plan_string, prefix_plan
     from keep_amd.synth import synth_tiles_device
 
-    def encode_all():
+    def encode_all(seed):
         out = torch.empty(n, 768, device=dev)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for a in range(0, n, 256):
             b = min(a + 256, n)
-            out[a:b] = model.encode_image(synth_tiles_device(a, b, dev, torch.bfloat16, seed=1000))
+            out[a:b] = model.encode_image(synth_tiles_device(a, b, dev, torch.bfloat16, seed=seed))
         torch.cuda.synchronize(dev)
         return out, time.perf_counter() - t0
 
-    own = (int(model.get_option("comp_full_blocks")), int(model.get_option("comp_mlp_blocks")))
+    def text_banks():
+        t64 = model.encode_text({k: v.to(dev) for k, v in toks64.items()})
+        tD = torch.cat([model.encode_text({k: v[i:i + 64].to(dev) for k, v in toksD.items()}) for i in range(0, distinct, 64)])
+        return t64, tD
+
+    own = model.get_plan()
+    depth = len(own)
     prec_was, sb_was = model._options["precision"], int(model._options.get("strict_blocks", 0))
     toks64, toksD = synth_prompts(64, 256, seed=1), synth_prompts(distinct, 256, seed=5)
-    out = {"workload": f"config 4 on one GPU: {n} synthetic tiles (device-generated, bf16), 64-prompt bank, {distinct} distinct prompts -> K = {K} x C = 4 "
-                       f"classifier bank ({K * 4} columns), prompt screening (topn {topn}), subtyping on a 256-px grid, detection (C = 2)",
-           "reference": "the engine's 'strict' mode on the same tiles (split products; 6.4e-7 of the fp32 oracle on config 3: tests/golden/c3_dual_tower.npz)"}
+    out = {"workload": f"config 4 on one GPU: {len(seeds)} synthetic slides of {n} tiles (device-generated, bf16; tile seeds {list(seeds)}), 64-prompt bank, "
+                       f"{distinct} distinct prompts -> K = {K} x C = 4 classifier bank ({K * 4} columns), prompt screening (topn {topn}), subtyping on a "
+                       "256-px grid, detection (C = 2)",
+           "reference": "the engine's 'strict' mode on the same tiles and prompts (split products; 6.4e-7 of the fp32 oracle on config 3: tests/golden/c3_dual_tower.npz)"}
+    plans = [own]
+    for st in settings or []:
+        pl = prefix_plan(depth, int(st[0]), int(st[1])) if len(st) == 2 and not isinstance(st[0], (tuple, list)) else [tuple(x) for x in st]
+        if pl != own:
+            plans.append(pl)
     try:
+        model.set_precision("comp", sb_was)
+        model.set_plan(own)
+        txt64_c, txtD_c = text_banks()                  # the comp side's text features: the benched mode (the text tower runs split products there too)
         model.set_precision("strict", sb_was)
-        txt64 = model.encode_text({k: v.to(dev) for k, v in toks64.items()})
-        txtD = torch.cat([model.encode_text({k: v[i:i + 64].to(dev) for k, v in toksD.items()}) for i in range(0, distinct, 64)])
-        f_s, t_s = encode_all()
-        out["strict_tiles_per_s"] = round(n / t_s, 1)
-        sim64_s, simD_s = model.similarity(f_s, txt64), model.similarity(f_s, txtD)
-        bank4 = rcc_shaped_bank(txtD, K)
-        bank2 = [c[:, :2].contiguous() for c in bank4]
-        side = int(n ** 0.5) + 1
-        idx = torch.arange(n)
-        coords = torch.stack([(idx % side) * 256, (idx // side) * 256], 1).numpy()
-        sc_s = wsi.prompt_scores(f_s, bank4, model=model)
-        ens4_s = wsi.zero_shot_prompt_select(bank4, f_s, topn, dev, model=model)
-        ens2_s = wsi.zero_shot_prompt_select(bank2, f_s, topn, dev, model=model)
-        label_s = int(wsi.zero_shot_subtyping(ens4_s, f_s, coords, 256, True, model=model))
-        p2_s = model.similarity(f_s, ens2_s.t().contiguous(), scale=10.0, mode="softmax")
-        ratio_s = wsi.zero_shot_detection(ens2_s, f_s, coords, 256, False, model=model)
-        todo = [own] + [tuple(st) for st in (settings or []) if tuple(st) != own]
-        for full, mlp in todo:
-            model.set_precision("comp", sb_was)
-            model.set_option("comp_full_blocks", full)
-            model.set_option("comp_mlp_blocks", mlp)
-            f, t = encode_all()
-            e = (f - f_s).norm(dim=1)
-            r = {"comp_full_blocks": full, "comp_mlp_blocks": mlp, "tiles_per_s_incl_tile_generation": round(n / t, 1),
-                 "feature_error_norm": {"max": float(f"{float(e.max()):.3e}"), "rms": float(f"{float(e.pow(2).mean().sqrt()):.3e}")},
-                 "cos_vs_64_prompts": diff_stats(model.similarity(f, txt64) - sim64_s),
-                 f"cos_vs_{distinct}_distinct_prompts": diff_stats(model.similarity(f, txtD) - simD_s)}
-            sc = wsi.prompt_scores(f, bank4, model=model)
-            ens4 = wsi.zero_shot_prompt_select(bank4, f, topn, dev, model=model)
-            ens2 = wsi.zero_shot_prompt_select(bank2, f, topn, dev, model=model)
-            r["screening_scores"] = {"max_abs_diff": float(f"{float((sc - sc_s).abs().max()):.3e}"),
-                                     "same_top_n": bool(set(torch.topk(sc, topn).indices.tolist()) == set(torch.topk(sc_s, topn).indices.tolist()))}
-            r["ensemble_classifier_max_abs_diff"] = float(f"{float((ens4 - ens4_s).abs().max()):.3e}")
-            r["slide_label"] = [int(wsi.zero_shot_subtyping(ens4, f, coords, 256, True, model=model)), label_s]
-            r["slide_label_equal"] = r["slide_label"][0] == label_s
-            ratio = wsi.zero_shot_detection(ens2, f, coords, 256, False, model=model)
-            p2 = model.similarity(f, ens2_s.t().contiguous(), scale=10.0, mode="softmax")           # same classifier on both sides: the tile-level comparison
-            flipped = (p2[:, 1] > 0.5) != (p2_s[:, 1] > 0.5)
-            cs = model.similarity(f_s, ens2_s.t().contiguous())
-            cosm = (cs[:, 1] - cs[:, 0]).abs()
-            r["tumour_ratio"] = [ratio, ratio_s]
-            r["tumour_tile_calls"] = {"tiles_whose_call_differs": int(flipped.sum()),
-                                      "largest_strict_cos_margin_of_such_a_tile": float(f"{(float(cosm[flipped].max()) if bool(flipped.any()) else 0.0):.3e}"),
-                                      "note": "a tile's tumour call is argmax over two cosines: it can only differ where the two are closer than twice the cosine tolerance "
-                                              "(KEEPModel.classify re-encodes such tiles when the labels themselves are the product)"}
-            r["prob_map_max_abs_diff"] = float(f"{float((p2 - p2_s).abs().max()):.3e}")
-            key = "headline_setting" if (full, mlp) == own else f"setting_{full}_{mlp}"
-            out[key] = r
-        h = out["headline_setting"]
-        out["max_abs_dcos_vs_strict"] = h["cos_vs_64_prompts"]["max_abs"]
-        out[f"max_abs_dcos_vs_strict_{distinct}_distinct_prompts"] = h[f"cos_vs_{distinct}_distinct_prompts"]["max_abs"]
-        out["within_1e-4"] = bool(h["cos_vs_64_prompts"]["over_1e-4"] == 0 and h[f"cos_vs_{distinct}_distinct_prompts"]["over_1e-4"] == 0)
+        txt64, txtD = text_banks()
+        per_seed, strict_rates, comp_rates = [], [], []
+        for si, seed in enumerate(seeds):
+            model.set_precision("strict", sb_was)
+            f_s, t_s = encode_all(seed)
+            strict_rates.append(n / t_s)
+            sim64_s, simD_s = model.similarity(f_s, txt64), model.similarity(f_s, txtD)
+            if si == 0:
+                bank4 = rcc_shaped_bank(txtD, K)
+                bank2 = [c[:, :2].contiguous() for c in bank4]
+                side = int(n ** 0.5) + 1
+                idx = torch.arange(n)
+                coords = torch.stack([(idx % side) * 256, (idx // side) * 256], 1).numpy()
+                sc_s = wsi.prompt_scores(f_s, bank4, model=model)
+                ens4_s = wsi.zero_shot_prompt_select(bank4, f_s, topn, dev, model=model)
+                ens2_s = wsi.zero_shot_prompt_select(bank2, f_s, topn, dev, model=model)
+                label_s = int(wsi.zero_shot_subtyping(ens4_s, f_s, coords, 256, True, model=model))
+                p2_s = model.similarity(f_s, ens2_s.t().contiguous(), scale=10.0, mode="softmax")
+                ratio_s = wsi.zero_shot_detection(ens2_s, f_s, coords, 256, False, model=model)
+            for pi, plan in enumerate(plans if si == 0 else plans[:1]):
+                model.set_precision("comp", sb_was)
+                model.set_plan(plan)
+                f, t = encode_all(seed)
+                e = (f - f_s).norm(dim=1)
+                pre = plan_prefix(plan)
+                r = {"tile_seed": seed, "comp_full_blocks": pre[0] if pre else None, "comp_mlp_blocks": pre[1] if pre else None, "plan": plan_string(plan),
+                     "tiles_per_s_incl_tile_generation": round(n / t, 1),
+                     "feature_error_norm": {"max": float(f"{float(e.max()):.3e}"), "rms": float(f"{float(e.pow(2).mean().sqrt()):.3e}")},
+                     "cos_vs_64_prompts": diff_stats(model.similarity(f, txt64_c) - sim64_s),
+                     f"cos_vs_{distinct}_distinct_prompts": diff_stats(model.similarity(f, txtD_c) - simD_s)}
+                if pi == 0:
+                    comp_rates.append(n / t)
+                    per_seed.append(r)
+                if si > 0:
+                    continue
+                sc = wsi.prompt_scores(f, bank4, model=model)
+                ens4 = wsi.zero_shot_prompt_select(bank4, f, topn, dev, model=model)
+                ens2 = wsi.zero_shot_prompt_select(bank2, f, topn, dev, model=model)
+                r["screening_scores"] = {"max_abs_diff": float(f"{float((sc - sc_s).abs().max()):.3e}"),
+                                         "same_top_n": bool(set(torch.topk(sc, topn).indices.tolist()) == set(torch.topk(sc_s, topn).indices.tolist()))}
+                r["ensemble_classifier_max_abs_diff"] = float(f"{float((ens4 - ens4_s).abs().max()):.3e}")
+                r["slide_label"] = [int(wsi.zero_shot_subtyping(ens4, f, coords, 256, True, model=model)), label_s]
+                r["slide_label_equal"] = r["slide_label"][0] == label_s
+                ratio = wsi.zero_shot_detection(ens2, f, coords, 256, False, model=model)
+                p2 = model.similarity(f, ens2_s.t().contiguous(), scale=10.0, mode="softmax")           # same classifier on both sides: the tile-level comparison
+                flipped = (p2[:, 1] > 0.5) != (p2_s[:, 1] > 0.5)
+                cs = model.similarity(f_s, ens2_s.t().contiguous())
+                cosm = (cs[:, 1] - cs[:, 0]).abs()
+                r["tumour_ratio"] = [ratio, ratio_s]
+                r["tumour_tile_calls"] = {"tiles_whose_call_differs": int(flipped.sum()),
+                                          "largest_strict_cos_margin_of_such_a_tile": float(f"{(float(cosm[flipped].max()) if bool(flipped.any()) else 0.0):.3e}"),
+                                          "note": "a tile's tumour call is argmax over two cosines: it can only differ where the two are closer than twice the cosine tolerance "
+                                                  "(KEEPModel.classify re-encodes such tiles when the labels themselves are the product)"}
+                r["prob_map_max_abs_diff"] = float(f"{float((p2 - p2_s).abs().max()):.3e}")
+                out["headline_setting" if pi == 0 else f"setting_{pi}_{plan_string(plan)}"] = r
+        keyD = f"cos_vs_{distinct}_distinct_prompts"
+        out["strict_tiles_per_s"] = round(sum(strict_rates) / len(strict_rates), 1)
+        out["tiles_per_s_incl_tile_generation"] = round(sum(comp_rates) / len(comp_rates), 1)
+        out["per_seed"] = [{"tile_seed": r["tile_seed"], "cos_vs_64_prompts": r["cos_vs_64_prompts"], keyD: r[keyD],
+                            "feature_error_norm": r["feature_error_norm"]} for r in per_seed]
+        out["worst_over_seeds"] = {"max_abs_dcos_64_prompts": max(r["cos_vs_64_prompts"]["max_abs"] for r in per_seed),
+                                   f"max_abs_dcos_{distinct}_distinct_prompts": max(r[keyD]["max_abs"] for r in per_seed),
+                                   "over_1e-4": sum(r["cos_vs_64_prompts"]["over_1e-4"] + r[keyD]["over_1e-4"] for r in per_seed),
+                                   "cosines_compared": sum(r["cos_vs_64_prompts"]["n"] + r[keyD]["n"] for r in per_seed),
+                                   "largest_max_over_rms": max(max(r["cos_vs_64_prompts"]["max_over_rms"], r[keyD]["max_over_rms"]) for r in per_seed)}
+        out["max_abs_dcos_vs_strict"] = out["worst_over_seeds"]["max_abs_dcos_64_prompts"]
+        out[f"max_abs_dcos_vs_strict_{distinct}_distinct_prompts"] = out["worst_over_seeds"][f"max_abs_dcos_{distinct}_distinct_prompts"]
+        out["within_1e-4"] = bool(out["worst_over_seeds"]["over_1e-4"] == 0)
     finally:
         model.set_precision({0: "fp16", 1: "strict", 2: "comp"}[int(prec_was)], sb_was)
-        model.set_option("comp_full_blocks", own[0])
-        model.set_option("comp_mlp_blocks", own[1])
+        model.set_plan(own)
     return out
 
 
@@ -348,6 +386,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the config-3 parity / config-3 / config-4 / config-5 legs")
     ap.add_argument("--no-c4", action="store_true", help="skip the 100 000-tile config-4 leg (about a minute)")
     ap.add_argument("--c4-tiles", type=int, default=100_000)
+    ap.add_argument("--c4-seeds", type=int, default=len(C4_SEEDS), help="number of 100 000-tile synthetic slides of the config-4 leg (about 50 s each)")
+    ap.add_argument("--budget", default=None, choices=["ladder", "measured"], help="re-run KEEPModel.calibrate with this budget after loading")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -377,6 +417,8 @@ def main():
     model.precision_name = args.precision
     model.load_state_dict(sd, strict=True)
     model.to(dev).eval()
+    if args.budget is not None and args.precision == "comp":
+        model.calibrate(budget=args.budget)
     for kv in args.opt:
         k, v = kv.split("=")
         model.set_option(k, float(v))
@@ -410,11 +452,18 @@ def main():
             own.append(el)
         return el
 
+    rccl_ranks_seen = None
     if use_dist:
+        # proof for the driver's SCALE record that RCCL really spans --gpus ranks: an all-reduce of ones over the nccl group
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(ones)
+        rccl_ranks_seen = int(round(float(ones.item())))
+        if rccl_ranks_seen != world:
+            raise SystemExit(f"RCCL all-reduce saw {rccl_ranks_seen} ranks, expected {world}")
         # every rank calibrates on its own at load: a scaling figure must not mix settings
         from keep_amd.distributed import assert_same_setting
-        assert_same_setting([model.get_option("precision"), model.get_option("comp_full_blocks"), model.get_option("comp_mlp_blocks")],
-                            "precision setting (precision, comp_full_blocks, comp_mlp_blocks)", device=dev)
+        assert_same_setting([model.get_option("precision")] + [float(v) for am in model.get_plan() for v in am],
+                            "precision setting (precision, per-block plan)", device=dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -513,7 +562,7 @@ def main():
             log(f"WARNING: {parity['argmax_mismatches']} config-3 labels differ from the fp32 oracle's -- the north star asks for bit-exact labels")
         if not args.no_c4 and args.precision == "comp":
             log(f"config 4 ({args.c4_tiles} tiles: the benched setting against the split-product mode) ...")
-            c4 = config4(model, dev, n=args.c4_tiles)
+            c4 = config4(model, dev, n=args.c4_tiles, seeds=C4_SEEDS[:max(1, args.c4_seeds)])
             if not c4["within_1e-4"]:
                 log("WARNING: config 4 holds cosines that differ from the split-product mode by more than 1e-4 in the benched setting")
         log("configs done")
@@ -529,13 +578,14 @@ def main():
 
         # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3 around the process (separate FETCH_SIZE / WRITE_SIZE passes, the guide's
         # gfx950 correction), so it is read from the committed summary of tools/refresh_profiles.sh and labelled with the library build it was taken on
-        traffic, traffic_src = None, None
-        for rnd in ("r04", "r03"):
+        traffic, traffic_src, traffic_tiles = None, None, None
+        for rnd in ("r05", "r04", "r03"):
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath)).get("vit.proj+fc2", {})
                     traffic = tj.get("bytes_per_launch")
+                    traffic_tiles = tj.get("tiles_per_launch", 128)      # the PMC passes run the two-lane bench: 128-tile launches
                     sha_path = os.path.join(ROOT, "profiles", f"{rnd}_lib_sha16.txt")
                     sha = open(sha_path).read().strip() if os.path.exists(sha_path) else "unrecorded"
                     traffic_src = (f"profiles/{rnd}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this kernel in the two-lane run "
@@ -547,7 +597,7 @@ def main():
         dom = [single.get(t, (0.0, 0, 0.0)) for t in DOMINANT_TAGS]
         dom_ms, dom_n, dom_fl = (sum(d[i] for d in dom) for i in range(3))
         roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", **rate(dom_ms, dom_n, dom_fl),
-                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic": traffic, "traffic_tiles_per_launch": traffic_tiles, "flops_tiles_per_launch": B, "traffic_source": traffic_src,
                     "timing": "single_stream_pass: HIP events around every launch of this kernel, on the stream it is launched on, 3 encode calls of 256 tiles with one "
                               "internal stream (nothing else on the GPU): a kernel figure, comparable with profiles/r04_rocprofv3_kernel_stats_single_stream.csv",
                     "share_of_single_stream_step": round(dom_ms / max(sum(v[0] for v in single.values()), 1e-9), 4) if single else None,
@@ -577,6 +627,7 @@ def main():
                        "tiles_per_gpu_per_step": B, "precision": args.precision,
                        "exchange": "RCCL all_gather of [256,768] fp32 embeddings per step" if use_dist else "none",
                        "comp_settings": {"comp_full_blocks": int(model.get_option("comp_full_blocks")), "comp_mlp_blocks": int(model.get_option("comp_mlp_blocks")),
+                                         "plan": plan_string(model.get_plan()), "plan_is_prefix": not bool(model.get_option("plan_custom")),
                                          "label_margin": model.get_option("label_margin"),
                                          "chosen_by": "KEEPModel.calibrate() at load_state_dict" if model.calibration else "built-in default"},
                        "mfma_frac_end_to_end": round(frac_e2e, 4)},
@@ -590,6 +641,8 @@ def main():
             line["parity"] = parity
         if c3 is not None or c4 is not None or c5 is not None:
             line["configs"] = {"c3": c3, "c4": c4, "c5": c5}
+        if rccl_ranks_seen is not None:
+            line["rccl_ranks_seen"] = rccl_ranks_seen      # sum of an all-reduced ones tensor over the nccl (= RCCL) group: must equal n_gpus
         if per_rank is not None:
             line["per_rank_tiles_per_s"] = per_rank
             line["exchange"] = exchange_cost

@@ -60,10 +60,25 @@ enum {
     KEEP_PREC_FP16 = 0,   /* fp16 MFMA operands, fp32 accumulate, fp32 residual/LN/softmax/GELU: fastest, cosines    */
                           /* within ~1.5e-4 of the fp32 reference (outside the 1e-4 north-star tolerance)          */
     KEEP_PREC_STRICT = 1, /* hi/lo split operands, 3 MFMA passes: fp32-class accuracy (4e-7), ~0.4x the speed       */
-    KEEP_PREC_COMP = 2    /* DEFAULT.  fp16 pass + the two first-order correction terms where the error budget     */
-                          /* needs them: image-tower MLP GEMMs of the first `comp_mlp_blocks` blocks on the MX-fp4  */
-                          /* MFMA pipe, attention side of the first `comp_full_blocks` blocks and the whole text    */
-                          /* tower as split products.  Cosines within 1e-4 of the fp32 reference.                   */
+    KEEP_PREC_COMP = 2    /* DEFAULT.  fp16 pass + first-order correction terms where the error budget needs them: */
+                          /* a per-block plan for the image tower (keep_set_block_precision: MLP GEMMs on the       */
+                          /* MX-fp4 MFMA pipe, attention side as split products), the whole text tower as split     */
+                          /* products.  Cosines within 1e-4 of the fp32 reference.                                  */
+};
+
+/* per-block treatment of the image tower in KEEP_PREC_COMP (keep_set_block_precision) */
+enum {
+    KEEP_ATTN_PLAIN = 0,          /* qkv, q/k/v storage, attention, proj: single fp16 passes                                       */
+    KEEP_ATTN_SPLIT = 1,          /* all four as split products (three fp16 passes; q/k/v and the attention output stored hi + lo)  */
+    KEEP_ATTN_SPLIT_COMPQKV = 2,  /* the same with the qkv GEMM as a compensated product (fp16 pass + MX-fp4 correction terms)      */
+    KEEP_ATTN_COMPQKV = 3         /* only the qkv GEMM compensated; attention and proj plain                                       */
+};
+enum {
+    KEEP_MLP_PLAIN = 0,           /* fc1 / fc2: single fp16 passes                                                                  */
+    KEEP_MLP_SPLIT = 1,           /* split products (three fp16 passes)                                                             */
+    KEEP_MLP_COMP = 2,            /* compensated: fp16 pass + both first-order terms W_lo A_hi + W_hi A_lo on the MX-fp4 pipe       */
+    KEEP_MLP_COMP_W = 3           /* compensated, weight-rounding term W_lo A_hi only (half the fp4 MFMAs and operand bytes; the    */
+                                  /* LayerNorm / GELU epilogues write Q(x_hi) only): removes the W half of the fp16 rounding error  */
 };
 
 const char* keep_version(void);
@@ -96,8 +111,10 @@ int keep_bert_layers(keep_handle* h);
 /* ---- options ----------------------------------------------------------------------------------
  *   "precision"       KEEP_PREC_COMP (default) | KEEP_PREC_FP16 | KEEP_PREC_STRICT
  *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
- *   "comp_full_blocks" KEEP_PREC_COMP: ViT blocks whose qkv / attention / proj run as split products (default 1)
- *   "comp_mlp_blocks"  KEEP_PREC_COMP: ViT blocks whose fc1 / fc2 run as compensated products (default 8)
+ *   "comp_full_blocks" KEEP_PREC_COMP, prefix shorthand: the first n ViT blocks get KEEP_ATTN_SPLIT, the rest KEEP_ATTN_PLAIN (default 1)
+ *   "comp_mlp_blocks"  KEEP_PREC_COMP, prefix shorthand: the first n ViT blocks get KEEP_MLP_COMP, the rest KEEP_MLP_PLAIN (default 8).
+ *                     Setting any of the four comp_* shorthands REWRITES the whole per-block plan (keep_set_block_precision below).
+ *   "plan_custom"      (read only) 1 if keep_set_block_precision changed the plan since the last shorthand
  *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
  *   "comp_qkv"         KEEP_PREC_COMP: 1 = the qkv GEMM of the split-attention blocks as a compensated product instead of a split one
  *                     (default 0: +0.9 % at equal settings, but calibrate() then needs more compensated MLP blocks -- a net loss)
@@ -131,6 +148,13 @@ int keep_bert_layers(keep_handle* h);
  */
 int keep_set_option(keep_handle* h, const char* name, double value);
 double keep_get_option(keep_handle* h, const char* name);
+/* The per-block plan of KEEP_PREC_COMP: block `block` (0 .. 63) of the image tower gets attention-side treatment `attn_mode` (KEEP_ATTN_*) and
+ * MLP treatment `mlp_mode` (KEEP_MLP_*); a negative mode leaves that half as it is.  Replaces nothing in the reference (which computes in fp32,
+ * quick_start/keep_inference.py:54-58): it is how this engine spends its precision budget -- where the fp16 rounding of a block matters for the
+ * final cosine is a property of the checkpoint, measured by KEEPModel.calibrate / tools/precision_budget.py.  Sub-batches below "comp_min_tiles"
+ * run split products wherever a compensated one is planned.  KEEP_PREC_STRICT / "strict_blocks" override the plan; KEEP_PREC_FP16 ignores it. */
+int keep_set_block_precision(keep_handle* h, int block, int attn_mode, int mlp_mode);
+int keep_get_block_precision(keep_handle* h, int block, int* attn_mode, int* mlp_mode);
 
 /* ---- preprocessing on the device -----------------------------------------------------------------
  * Replaces: transforms.Resize(224, BICUBIC) + CenterCrop((224,224))  (quick_start/keep_inference.py:88-90) for raw uint8
@@ -245,14 +269,14 @@ int keep_profile_reset(keep_handle* h);
  *   epi 0: out[M,N] = acc+bias            1: gelu(acc+bias)
  *       2: out = resid + ls*(acc+bias)    4: out = resid + acc + bias      (resid, ls fp32)
  *   split 1 runs the 3-pass hi/lo product, split 2 the compensated product (fp16 pass + MX-fp4 correction terms;
- *   N % 256 == 0, K % 128 == 0, K >= 256, epi 0..2).  Outputs of epi 0/1 are the fp16-rounded values (hi, or hi+lo when
+ *   N % 256 == 0, K % 128 == 0, K >= 256, epi 0..2), split 3 the compensated product with the W_lo A_hi term only (K >= 512).  Outputs of epi 0/1 are the fp16-rounded values (hi, or hi+lo when
  *   split != 0) converted back to fp32. */
 int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* bias, const float* ls,
                    const float* resid, int64_t M, int64_t N, int64_t K, int epi, int split, float* out,
                    void* stream);
 /* One MLP half of a ViT block through the tower's own kernels (timm Block: x + ls2 * fc2(gelu(fc1(norm2(x))))):
  *   LayerNorm (writes the fp16 operand and, per mode, its lo plane / MX-fp4 side planes) -> fc1 + GELU -> fc2 + LayerScale + residual.
- *   mode 0 plain fp16 | 1 split | 2 compensated.  x, out fp32 [M, D]; D in {768, 1024}; F % 256 == 0. */
+ *   mode = KEEP_MLP_*: 0 plain fp16 | 1 split | 2 compensated | 3 compensated, W_lo term only.  x, out fp32 [M, D]; D in {768, 1024}; F % 256 == 0. */
 int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* ln_b, const float* fc1_w, const float* fc1_b,
                 const float* fc2_w, const float* fc2_b, const float* ls, int64_t M, int64_t D, int64_t F, int mode, float* out,
                 void* stream);

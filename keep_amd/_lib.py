@@ -18,6 +18,8 @@ KEEP_OK, KEEP_EINVAL, KEEP_ESTATE, KEEP_EKEY, KEEP_EHIP, KEEP_EUNSUPPORTED, KEEP
 PIX_F32, PIX_F16, PIX_BF16, PIX_U8_HWC = 0, 1, 2, 3
 SIM_RAW, SIM_ARGMAX, SIM_SOFTMAX, SIM_SOFTMAX_F16, SIM_TOP2SCORE = 0, 1, 2, 3, 4
 PREC_FP16, PREC_STRICT, PREC_COMP = 0, 1, 2
+ATTN_PLAIN, ATTN_SPLIT, ATTN_SPLIT_COMPQKV, ATTN_COMPQKV = 0, 1, 2, 3        # keep_set_block_precision: attention side of a ViT block
+MLP_PLAIN, MLP_SPLIT, MLP_COMP, MLP_COMP_W = 0, 1, 2, 3                      # ... and its MLP
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 
@@ -34,6 +36,8 @@ SIGNATURES = {
     "keep_bert_layers": (_i32, [_vp]),
     "keep_set_option": (_i32, [_vp, C.c_char_p, C.c_double]),
     "keep_get_option": (C.c_double, [_vp, C.c_char_p]),
+    "keep_set_block_precision": (_i32, [_vp, _i32, _i32, _i32]),
+    "keep_get_block_precision": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "keep_reserve": (_i32, [_vp, _i64, _i64, _i64]),
     "keep_workspace_bytes": (_i64, [_vp]),
     "keep_encode_image": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),

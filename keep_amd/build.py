@@ -18,7 +18,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkeep_hip.so")
-SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "engine.hip"]
+SOURCES = ["gemm_f16.hip", "gemm_f16_v2.hip", "gemm_f16_skinny.hip", "attention.hip", "rowops.hip", "sgemm_f32.hip", "wsi.hip", "launch_util.hip", "engine.hip"]
 # -falign-loops=64: the hot loops start on an instruction-cache line.  Without it a functionally identical edit elsewhere in a kernel moved the
 # K loop of the GEMM by a few dwords and the whole encoder by up to 3 % (measured: DESIGN.md section 4); with it +0.5 % and reproducible.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-falign-loops=64", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value",
@@ -104,6 +104,9 @@ def _build(OUT: str, objdir: str, defines, verbose: bool, force: bool = False) -
         return obj
 
     srcs = _sources(defines)
+    for f in os.listdir(objdir):                      # objects of sources that have left the tree are not carried along
+        if f.endswith(".o") and f.replace(".o", ".hip") not in srcs:
+            os.remove(os.path.join(objdir, f))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 2)) as ex:
         objs = list(ex.map(compile_one, srcs))
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)

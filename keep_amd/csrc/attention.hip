@@ -500,32 +500,17 @@ void attention_pers_kernel(AttnParams p) {
 template <int NT>
 int launch_pers(const AttnParams& p, hipStream_t s) {
     constexpr size_t bytes = (size_t)2 * ((size_t)NT * 16 * HD + (size_t)att_kp2(NT) * HD) * 2 + (size_t)NT * 16 * 4;
-    static unsigned long long done = 0;
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev >= 64) return -2;
-    if (!((done >> dev) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pers_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -2;
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-        done |= 1ull << dev;
-    }
+    if (!keep_lds_opt_in(reinterpret_cast<const void*>(&attention_pers_kernel<NT>), bytes)) return -2;     // refused: the caller falls back to one pair per workgroup
+    const int ncu = keep_num_cus();
     const int items = p.batch * p.heads;
-    hipLaunchKernelGGL((attention_pers_kernel<NT>), dim3(items < cus[dev] ? items : cus[dev]), dim3(1024), bytes, s, p);
+    hipLaunchKernelGGL((attention_pers_kernel<NT>), dim3(items < ncu ? items : ncu), dim3(1024), bytes, s, p);
     return 0;
 }
 
 template <int NT, bool SPLIT, int NW>
 int launch_one(const AttnParams& p, hipStream_t s) {
     constexpr size_t bytes = att_lds_bytes(NT, SPLIT);
-    static unsigned long long done = 0;              // hipFuncSetAttribute is per device: bit d = device d opted in
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -2;
-    if (dev >= 64 || !((done >> dev) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NT, SPLIT, NW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return -2;
-        if (dev < 64) done |= 1ull << dev;
-    }
+    if (!keep_lds_opt_in(reinterpret_cast<const void*>(&attention_kernel<NT, SPLIT, NW>), bytes)) return -2;
     hipLaunchKernelGGL((attention_kernel<NT, SPLIT, NW>), dim3(p.batch * p.heads), dim3(NW * 64), bytes, s, p);
     return 0;
 }

@@ -100,8 +100,10 @@ struct GemmParams {
     const f16* w_hi; const f16* w_lo;     // weights [N][K], same layout as A
     int M, N, K;                          // K = per-segment depth; multiples: N%128==0, K%64==0
     int nseg;                             // 1: A_hi*W_hi ; 3: A_hi*W_hi + A_lo*W_hi + A_hi*W_lo
-    // comp != 0: after the fp16 pass the two correction terms run on the MX-fp4 pipe (quant4.h): needs the fp4 side planes
-    // of both operands, K % 64 == 0, nseg == 1, and the 256x256 kernel (the small-M paths use nseg = 3 instead)
+    // comp != 0: after the fp16 pass the correction terms run on the MX-fp4 pipe (quant4.h): needs the fp4 side planes
+    // of both operands, K % 128 == 0, nseg == 1, and the 256x256 kernel (the small-M paths use nseg = 3 instead).
+    //   2 (or any value but 1): both first-order terms  W_lo A_hi + W_hi A_lo
+    //   1: the weight-rounding term W_lo A_hi only (reads plane 0 of a_q and plane 1 of w_q; K >= 512); with out_q set, writes plane 0 only
     int comp;
     const unsigned char* a_q; const unsigned char* a_sc;
     const unsigned char* w_q; const unsigned char* w_sc;
@@ -160,6 +162,7 @@ struct LnParams {
     int out_kt;
     float* out_f32; int64_t out_f32_stride;   // nullable
     unsigned char* out_q; unsigned char* out_sc;   // nullable: fp4 side planes of the output (quant4.h), blk path only; needs out_lo semantics internally
+    int out_q_hi_only;                    // 1: only plane 0 (Q(x_hi)) and its scales are written (the consumer is a one-term compensated GEMM)
     const KeepTune* tune;
 };
 int launch_layernorm(const LnParams& p, hipStream_t s);
@@ -220,5 +223,10 @@ void launch_gather_tiles(const void* src, int64_t tile_bytes, const int* list, i
 void launch_scatter_rows(const float* src, const int* list, int n, int D, float* dst, hipStream_t s);
 void launch_refine(const float* probs, const long long* coords, int n, int C, long long patch, int overlap,
                    unsigned long long* keys, int* first, unsigned table_size, float* out, int* is_first, hipStream_t s);
+
+// launch_util.hip: per-(kernel, device) opt-in to more than 64 KiB of dynamic LDS (cached, thread-safe; a refusal leaves no sticky HIP error behind),
+// and the CU count of the current device
+bool keep_lds_opt_in(const void* kernel, size_t bytes);
+int keep_num_cus();
 
 enum PixelDType : int { PIX_F32 = 0, PIX_F16 = 1, PIX_BF16 = 2, PIX_U8_HWC = 3 };

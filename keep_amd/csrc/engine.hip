@@ -106,6 +106,22 @@ struct keep_handle {
                                  // but block 0's qkv is where the error budget is tightest (the 3 % of the rounding variance the fp4 terms leave is
                                  // amplified by all 24 blocks): calibrate() then needs 10 compensated MLP blocks instead of 6 -- a net loss.  Off.
     int comp_qkv_from = 1 << 20; // the same for the split-attention blocks with index >= this only (block 0 keeps its three-pass qkv)
+    // The per-block plan of KEEP_PREC_COMP (keep_set_block_precision; the four options above are prefix shorthands that rewrite it):
+    //   attn_mode[i]  attention side of block i: KEEP_ATTN_PLAIN | KEEP_ATTN_SPLIT (qkv, q/k/v storage, attention, proj as split products) |
+    //                 KEEP_ATTN_SPLIT_COMPQKV (the same with the qkv GEMM as a compensated product) | KEEP_ATTN_COMPQKV (compensated qkv only)
+    //   mlp_mode[i]   fc1 / fc2 of block i: KEEP_MLP_PLAIN | KEEP_MLP_SPLIT | KEEP_MLP_COMP (both MX-fp4 correction terms) | KEEP_MLP_COMP_W (the W_lo term only)
+    // Which block gets what is a measured, per-checkpoint decision (tools/precision_budget.py, KEEPModel.calibrate).
+    static constexpr int MAX_BLOCKS = 64;
+    unsigned char attn_mode[MAX_BLOCKS] = {}, mlp_mode[MAX_BLOCKS] = {};
+    bool plan_custom = false;    // keep_set_block_precision was called since the last prefix option
+    void plan_from_prefix() {
+        for (int i = 0; i < MAX_BLOCKS; ++i) {
+            attn_mode[i] = i < comp_full_blocks ? ((comp_qkv || i >= comp_qkv_from) ? KEEP_ATTN_SPLIT_COMPQKV : KEEP_ATTN_SPLIT) : KEEP_ATTN_PLAIN;
+            mlp_mode[i] = i < comp_mlp_blocks ? KEEP_MLP_COMP : KEEP_MLP_PLAIN;
+        }
+        plan_custom = false;
+    }
+    keep_handle() { plan_from_prefix(); }
     // keep_classify: tiles whose top-2 cosine margin is below this are re-encoded in KEEP_PREC_STRICT before their label is taken.
     // Default = 2 x the north-star tolerance (both cosines of a pair can move by 1e-4 in opposite directions) + 25 %.
     float label_margin = 2.5e-4f;
@@ -154,13 +170,25 @@ struct keep_handle {
     // variance, blocks 0-1 52 %, and outside them the MLP GEMMs carry > 80 %):
     //   attention side (qkv, q/k/v storage, softmax probabilities, proj) of block i: split product or plain
     //   MLP (fc1, fc2) of block i: 0 plain | 1 split (three fp16 passes) | 2 compensated (fp16 pass + two MX-fp4 correction terms)
-    bool vit_attn_split(int i) const {
-        return precision == KEEP_PREC_STRICT || i < strict_blocks || (precision == KEEP_PREC_COMP && i < comp_full_blocks);
+    int plan_attn(int i) const { return (precision == KEEP_PREC_COMP && i >= 0 && i < MAX_BLOCKS) ? attn_mode[i] : KEEP_ATTN_PLAIN; }
+    // lanes too small for the 256x256 kernel take split products wherever a compensated one is asked for (they run on the small-M / K-sliced kernels)
+    bool vit_attn_split(int i, int lane_tiles = 1 << 20) const {
+        if (precision == KEEP_PREC_STRICT || i < strict_blocks) return true;
+        const int a = plan_attn(i);
+        return a == KEEP_ATTN_SPLIT || a == KEEP_ATTN_SPLIT_COMPQKV || (a == KEEP_ATTN_COMPQKV && !(lane_tiles >= comp_min_tiles && vit_has_q));
     }
+    bool vit_qkv_comp(int i, int lane_tiles) const {
+        if (precision != KEEP_PREC_COMP || i < strict_blocks || !(lane_tiles >= comp_min_tiles && vit_has_q)) return false;
+        const int a = plan_attn(i);
+        return a == KEEP_ATTN_SPLIT_COMPQKV || a == KEEP_ATTN_COMPQKV;
+    }
+    // fc1 / fc2 of block i: 0 plain | 1 split (three fp16 passes) | 2 compensated (both MX-fp4 terms) | 3 compensated, W_lo term only
     int vit_mlp_mode(int i, int lane_tiles) const {
-        if (precision == KEEP_PREC_STRICT || i < strict_blocks) return 1;
-        if (precision == KEEP_PREC_COMP && i < comp_mlp_blocks) return (lane_tiles >= comp_min_tiles && vit_has_q) ? 2 : 1;
-        return 0;
+        if (precision == KEEP_PREC_STRICT || i < strict_blocks) return KEEP_MLP_SPLIT;
+        if (precision != KEEP_PREC_COMP || i < 0 || i >= MAX_BLOCKS) return KEEP_MLP_PLAIN;
+        const int m = mlp_mode[i];
+        if (m == KEEP_MLP_COMP || m == KEEP_MLP_COMP_W) return (lane_tiles >= comp_min_tiles && vit_has_q) ? m : KEEP_MLP_SPLIT;
+        return m;
     }
     // the text tower is 1 % of a slide's work: in the compensated mode it simply runs split products throughout
     // (the split attention kernel covers T <= 256, the reference's max_length; in the compensated mode longer sequences fall back to
@@ -169,7 +197,12 @@ struct keep_handle {
     bool txt_must_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
     bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
     bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 128 == 0)
-    bool any_comp() const { return precision == KEEP_PREC_COMP && vit_has_q && (comp_mlp_blocks > 0 || (comp_full_blocks > 0 && (comp_qkv || comp_qkv_from < comp_full_blocks))); }
+    bool any_comp() const {
+        if (precision != KEEP_PREC_COMP || !vit_has_q) return false;
+        for (int i = 0; i < MAX_BLOCKS && i < (vit_depth ? vit_depth : MAX_BLOCKS); ++i)
+            if (mlp_mode[i] >= KEEP_MLP_COMP || attn_mode[i] >= KEEP_ATTN_SPLIT_COMPQKV) return true;
+        return false;
+    }
 
     bool prof_on(int tag) const { return prof_mode == 2 || (prof_mode == 1 && ((prof_mask >> tag) & 1ull)); }
     void prof_add_flops(int tag, double f) { if (prof_on(tag)) prof_flops[tag] += f; }
@@ -409,9 +442,10 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
     // Exact (same arithmetic on the rows that matter); the skipped FLOPs still count as algorithmic work.
     const bool cls_only = (i == h->vit_depth - 1) && h->cls_tail;
-    const bool sp = h->vit_attn_split(i);                              // qkv / attention / proj as split products
-    const int mlp = h->vit_mlp_mode(i, cls_only ? 0 : Bc);             // fc1 / fc2: 0 plain, 1 split, 2 compensated (MX-fp4 corrections)
-    const bool mlp_lo = mlp == 1, mlp_q = mlp == 2;
+    const bool sp = h->vit_attn_split(i, Bc);                          // qkv / attention / proj as split products
+    const int mlp = h->vit_mlp_mode(i, cls_only ? 0 : Bc);             // fc1 / fc2: 0 plain, 1 split, 2 compensated (both MX-fp4 terms), 3 compensated (W_lo term only)
+    const bool mlp_lo = mlp == KEEP_MLP_SPLIT, mlp_q = mlp == KEEP_MLP_COMP || mlp == KEEP_MLP_COMP_W;
+    const int mlp_comp = mlp == KEEP_MLP_COMP_W ? 1 : 2;               // GemmParams.comp of the block's fc1 / fc2
 #ifdef KEEP_DIAGNOSTICS
     const bool skip_ln = h->dbg_skip_ln == 1 && h->dbg_calls > 3;
 #else
@@ -419,7 +453,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
 #endif
     // qkv of a split-attention block in the compensated mode: fp16 pass + MX-fp4 correction terms instead of three fp16 passes (lanes
     // large enough for the 256x256 kernel; LayerNorm-1 then writes the fp4 planes of its output instead of the lo plane)
-    const bool qkv_q = sp && h->precision == KEEP_PREC_COMP && i >= h->strict_blocks && (h->comp_qkv || i >= h->comp_qkv_from) && Bc >= h->comp_min_tiles && b.qkv->q && ws.xn_q && !L.xn_ready;
+    const bool qkv_q = h->vit_qkv_comp(i, Bc) && b.qkv->q && ws.xn_q && !L.xn_ready;
     LnParams ln{};
     ln.tune = &h->tune;
     ln.x = ws.resid; ln.x_stride = D; ln.rows = M; ln.D = D; ln.eps = 1e-6f;
@@ -432,11 +466,11 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     }
     L.xn_ready = false;
     {
-        const int tag = sp ? T_VIT_QKV_X : T_VIT_QKV;
+        const int tag = (sp || qkv_q) ? T_VIT_QKV_X : T_VIT_QKV;
         Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, b.qkv_b);
         p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
-        if (qkv_q) { p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.qkv->q; p.w_sc = b.qkv->sc; }
+        if (qkv_q) { p.comp = 2; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.qkv->q; p.w_sc = b.qkv->sc; }
         if (run_gemm(h, tag, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "qkv GEMM launch failed");
     }
     mark(1);
@@ -466,7 +500,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         L.cls_compact = true;
     }
     ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = mlp_lo ? xn_lo : nullptr;
-    ln.out_q = mlp_q ? ws.xn_q : nullptr; ln.out_sc = mlp_q ? ws.xn_sc : nullptr;
+    ln.out_q = mlp_q ? ws.xn_q : nullptr; ln.out_sc = mlp_q ? ws.xn_sc : nullptr; ln.out_q_hi_only = mlp == KEEP_MLP_COMP_W;
     ln.gamma = b.n2w; ln.beta = b.n2b;
     int did;
     {
@@ -489,7 +523,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, b.fc1_b);
         p.out_hi = mlp_hi; p.out_lo = mlp_lo ? mlp_lo_p : nullptr; p.out_kt = h->vit_F / 32;
         if (mlp_q) {
-            p.comp = 1; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
+            p.comp = mlp_comp; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
             p.out_q = ws.mlp_q; p.out_sc = ws.mlp_sc;
         }
         if (run_gemm(h, tag, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "fc1 GEMM launch failed");
@@ -500,11 +534,11 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, b.fc2_b);
         p.ls = b.ls2; p.resid = resid;
-        if (mlp_q) { p.comp = 1; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
+        if (mlp_q) { p.comp = mlp_comp; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
         if (i + 1 < h->vit_depth && !cls_only) {        // next block's LayerNorm-1 reads exactly the rows written here
             const VitBlock& nb = h->vblocks[i + 1];
-            ln.x = ws.resid; ln.rows = M; ln.out_hi = ws.xn_hi; ln.out_lo = h->vit_attn_split(i + 1) ? ws.xn_lo : nullptr;
-            ln.out_q = nullptr; ln.out_sc = nullptr;
+            ln.x = ws.resid; ln.rows = M; ln.out_hi = ws.xn_hi; ln.out_lo = h->vit_attn_split(i + 1, Bc) ? ws.xn_lo : nullptr;
+            ln.out_q = nullptr; ln.out_sc = nullptr; ln.out_q_hi_only = 0;
             ln.gamma = nb.n1w; ln.beta = nb.n1b;
             offer_ln(p, ln);
         }
@@ -774,6 +808,7 @@ int finalize_vit(keep_handle* h) {
     HIPCHK(h, hipStreamSynchronize(nullptr));
     h->vit_has_q = true;
     for (auto& b : h->vblocks) if (!b.fc1->q || !b.fc2->q) h->vit_has_q = false;
+    if (depth > keep_handle::MAX_BLOCKS) return h->fail(KEEP_EUNSUPPORTED, "image tower of %d blocks (the per-block precision plan holds %d)", depth, keep_handle::MAX_BLOCKS);
     h->vit_depth = depth; h->vit_D = (int)D; h->vit_heads = (int)(D / 64); h->vit_F = (int)F; h->proj_dim = (int)PJ;
     return KEEP_OK;
 }
@@ -1130,10 +1165,11 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     if (n == "label_margin") { if (!(value >= 0.0) || value > 2.0) return h->fail(KEEP_EINVAL, "label_margin must be in [0, 2]"); h->label_margin = (float)value; return KEEP_OK; }
     if (n == "precision") { if (v != KEEP_PREC_FP16 && v != KEEP_PREC_STRICT && v != KEEP_PREC_COMP) return h->fail(KEEP_EINVAL, "precision %d", v); h->precision = v; }
     else if (n == "strict_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "strict_blocks < 0"); h->strict_blocks = v; }
-    else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; }
-    else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; }
-    else if (n == "comp_qkv") { h->comp_qkv = v ? 1 : 0; }
-    else if (n == "comp_qkv_from") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_qkv_from < 0"); h->comp_qkv_from = v; }
+    // the four prefix shorthands rewrite the whole per-block plan (a plan set block by block through keep_set_block_precision is replaced)
+    else if (n == "comp_full_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_full_blocks < 0"); h->comp_full_blocks = v; h->plan_from_prefix(); }
+    else if (n == "comp_mlp_blocks") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_mlp_blocks < 0"); h->comp_mlp_blocks = v; h->plan_from_prefix(); }
+    else if (n == "comp_qkv") { h->comp_qkv = v ? 1 : 0; h->plan_from_prefix(); }
+    else if (n == "comp_qkv_from") { if (v < 0) return h->fail(KEEP_EINVAL, "comp_qkv_from < 0"); h->comp_qkv_from = v; h->plan_from_prefix(); }
     else if (n == "comp_min_tiles") { if (v < 24) return h->fail(KEEP_EINVAL, "comp_min_tiles must be >= 24 (the compensated product needs the 256x256 kernel)"); h->comp_min_tiles = v; }
     else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
@@ -1178,6 +1214,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "comp_min_tiles") return h->comp_min_tiles;
     if (n == "comp_qkv") return h->comp_qkv;
     if (n == "comp_qkv_from") return h->comp_qkv_from;
+    if (n == "plan_custom") return h->plan_custom ? 1 : 0;
     if (n == "max_tiles") return h->max_tiles;
     if (n == "max_prompts") return h->max_prompts;
     if (n == "gemm_impl") return t.gemm_impl;
@@ -1193,6 +1230,24 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "lane0_permille") return h->lane0_permille;
     if (n == "cls_tail") return h->cls_tail;
     return -1;
+}
+
+int keep_set_block_precision(keep_handle* h, int block, int attn_mode, int mlp_mode) {
+    if (!h) return KEEP_EINVAL;
+    if (block < 0 || block >= keep_handle::MAX_BLOCKS) return h->fail(KEEP_EINVAL, "block %d outside 0..%d", block, keep_handle::MAX_BLOCKS - 1);
+    if (attn_mode > KEEP_ATTN_COMPQKV || mlp_mode > KEEP_MLP_COMP_W) return h->fail(KEEP_EINVAL, "attn_mode %d / mlp_mode %d (0..3, negative = leave)", attn_mode, mlp_mode);
+    ++h->opt_epoch;               // captured graphs bake the plan in
+    if (attn_mode >= 0) h->attn_mode[block] = (unsigned char)attn_mode;
+    if (mlp_mode >= 0) h->mlp_mode[block] = (unsigned char)mlp_mode;
+    h->plan_custom = true;
+    return KEEP_OK;
+}
+int keep_get_block_precision(keep_handle* h, int block, int* attn_mode, int* mlp_mode) {
+    if (!h) return KEEP_EINVAL;
+    if (block < 0 || block >= keep_handle::MAX_BLOCKS) return h->fail(KEEP_EINVAL, "block %d outside 0..%d", block, keep_handle::MAX_BLOCKS - 1);
+    if (attn_mode) *attn_mode = h->attn_mode[block];
+    if (mlp_mode) *mlp_mode = h->mlp_mode[block];
+    return KEEP_OK;
 }
 
 int keep_reserve(keep_handle* h, int64_t tiles, int64_t prompts, int64_t seq) {
@@ -1422,7 +1477,7 @@ int keep_prompt_scores(keep_handle* h, const float* feats, const float* bank, in
         p.tune = &h->tune;
         p.a_hi = (f16*)(a + o_ahi); p.a_lo = (f16*)(a + o_alo); p.w_hi = (f16*)(a + o_whi); p.w_lo = (f16*)(a + o_wlo);
         p.M = (int)N; p.N = (int)KCp; p.K = (int)D; p.nseg = comp ? 1 : 3; p.patches_per_img = 196;
-        if (comp) { p.comp = 1; p.a_q = (unsigned char*)(a + o_aq); p.a_sc = (unsigned char*)(a + o_asc); p.w_q = (unsigned char*)(a + o_wq); p.w_sc = (unsigned char*)(a + o_wsc); }
+        if (comp) { p.comp = 2; p.a_q = (unsigned char*)(a + o_aq); p.a_sc = (unsigned char*)(a + o_asc); p.w_q = (unsigned char*)(a + o_wq); p.w_sc = (unsigned char*)(a + o_wsc); }
         p.top2_c = (int)C; p.top2_partial = (float*)(a + o_part); p.top2_kpad = (int)kpad;
         h->prof_add_flops(T_SIM, 2.0 * N * (double)KC * D);
         if (launch_gemm_f16(p, EPI_TOP2, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "fused prompt screening launch failed");
@@ -1575,10 +1630,10 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     f16* w_hi = t.get<f16>(we); f16* w_lo = t.get<f16>(we);
     f16* o_hi = t.get<f16>(oe); f16* o_lo = t.get<f16>(oe);
     if (!a_hi || !a_lo || !w_hi || !w_lo || !o_hi || !o_lo) return h->fail(KEEP_ENOMEM, "temp alloc");
-    const bool comp = split == 2;
+    const bool comp = split == 2 || split == 3;          // 3: the W_lo term only (K >= 512)
     unsigned char *a_q = nullptr, *a_sc = nullptr, *w_q = nullptr, *w_sc = nullptr;
     if (comp) {
-        if (N % 256 || K % 128 || K < 256 || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%128==0, K>=256 and epilogue 0/1/2");
+        if (N % 256 || K % 128 || K < (split == 3 ? 512 : 256) || epi == EPI_RESID_F32) return h->fail(KEEP_EUNSUPPORTED, "compensated linear needs N%%256==0, K%%128==0, K>=256 (512 for the one-term form) and epilogue 0/1/2");
         a_q = t.get<unsigned char>(keepk::q4_data_bytes(M, K)); a_sc = t.get<unsigned char>(keepk::q4_scale_bytes(M, K));
         w_q = t.get<unsigned char>(keepk::q4_data_bytes(N, K)); w_sc = t.get<unsigned char>(keepk::q4_scale_bytes(N, K));
         if (!a_q || !a_sc || !w_q || !w_sc) return h->fail(KEEP_ENOMEM, "temp alloc");
@@ -1589,18 +1644,18 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
     p.tune = &h->tune;
     p.a_hi = a_hi; p.a_lo = a_lo; p.w_hi = w_hi; p.w_lo = w_lo; p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.nseg = (split == 1) ? 3 : 1; p.bias = bias; p.ls = ls; p.patches_per_img = 196;
-    if (comp) { p.comp = 1; p.a_q = a_q; p.a_sc = a_sc; p.w_q = w_q; p.w_sc = w_sc; }
+    if (comp) { p.comp = split == 3 ? 1 : 2; p.a_q = a_q; p.a_sc = a_sc; p.w_q = w_q; p.w_sc = w_sc; }
     p.splitk_ws = t.get<float>(SKINNY_WS_BYTES / 4); p.splitk_bytes = SKINNY_WS_BYTES;      // auto mode may take a split-K path (small or mid-size M), as the towers do
     if (!p.splitk_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
     int launch_rc = 0;
     auto launch = [&](const GemmParams& q) { launch_rc = launch_gemm_f16(q, epi, s); };
     if (epi == EPI_F16 || epi == EPI_GELU_F16) {
-        p.out_hi = o_hi; p.out_lo = split ? o_lo : nullptr;
+        p.out_hi = o_hi; p.out_lo = (split == 1 || split == 2) ? o_lo : nullptr;
         // as in the towers: the GELU output feeds another GEMM (blk layout), the plain one feeds attention (row-major)
         p.out_kt = (epi == EPI_GELU_F16) ? (int)(N / 32) : 0;
         launch(p);
-        if (p.out_kt) launch_unblockify_f32(o_hi, split ? o_lo : nullptr, out, (int)M, (int)N, s);
-        else planes_to_f32(o_hi, split ? o_lo : nullptr, out, M * N, s);
+        if (p.out_kt) launch_unblockify_f32(o_hi, p.out_lo, out, (int)M, (int)N, s);
+        else planes_to_f32(o_hi, p.out_lo, out, M * N, s);
     } else if (epi == EPI_RESID_LS) {
         HIPCHK(h, hipMemcpyAsync(out, resid, M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
         p.resid = out;
@@ -1617,11 +1672,12 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
 int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* ln_b, const float* fc1_w, const float* fc1_b,
                 const float* fc2_w, const float* fc2_b, const float* ls, int64_t M, int64_t D, int64_t F, int mode, float* out, void* stream) {
     if (!h || !x || !ln_w || !ln_b || !fc1_w || !fc1_b || !fc2_w || !fc2_b || !ls || !out) return h ? h->fail(KEEP_EINVAL, "null pointer") : KEEP_EINVAL;
-    if (M < 1 || (D != 768 && D != 1024) || F % 256 || F < 256 || mode < 0 || mode > 2) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: D in {768, 1024}, F %% 256 == 0, mode 0..2");
+    if (M < 1 || (D != 768 && D != 1024) || F % 256 || F < 256 || mode < 0 || mode > 3) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: D in {768, 1024}, F %% 256 == 0, mode 0..3");
     KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     Tmp t;
-    const bool lo = mode == 1, q = mode == 2;
+    const bool lo = mode == 1, q = mode == 2 || mode == 3;
+    const int cmode = mode == 3 ? 1 : 2;                 // GemmParams.comp: the W_lo term only | both terms
     f16 *w1h = t.get<f16>(F * D), *w1l = t.get<f16>(F * D), *w2h = t.get<f16>(D * F), *w2l = t.get<f16>(D * F);
     f16 *xh = t.get<f16>(blk_elems(M, D)), *xl = t.get<f16>(blk_elems(M, D)), *mh = t.get<f16>(blk_elems(M, F)), *ml = t.get<f16>(blk_elems(M, F));
     unsigned char *w1q = t.get<unsigned char>(keepk::q4_data_bytes(F, D)), *w1s = t.get<unsigned char>(keepk::q4_scale_bytes(F, D));
@@ -1636,19 +1692,19 @@ int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* 
     LnParams ln{};
     ln.tune = &h->tune;
     ln.x = x; ln.x_stride = D; ln.rows = (int)M; ln.D = (int)D; ln.eps = 1e-6f; ln.gamma = ln_w; ln.beta = ln_b;
-    ln.out_hi = xh; ln.out_lo = lo ? xl : nullptr; ln.out_kt = (int)(D / 32); ln.out_q = q ? xq : nullptr; ln.out_sc = q ? xs : nullptr;
+    ln.out_hi = xh; ln.out_lo = lo ? xl : nullptr; ln.out_kt = (int)(D / 32); ln.out_q = q ? xq : nullptr; ln.out_sc = q ? xs : nullptr; ln.out_q_hi_only = mode == 3;
     if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: layernorm");
     GemmParams p{};
     p.tune = &h->tune; p.patches_per_img = 196; p.splitk_ws = ws; p.splitk_bytes = SKINNY_WS_BYTES;
     p.a_hi = xh; p.a_lo = xl; p.w_hi = w1h; p.w_lo = w1l; p.M = (int)M; p.N = (int)F; p.K = (int)D; p.nseg = lo ? 3 : 1; p.bias = fc1_b;
     p.out_hi = mh; p.out_lo = lo ? ml : nullptr; p.out_kt = (int)(F / 32);
-    if (q) { p.comp = 1; p.a_q = xq; p.a_sc = xs; p.w_q = w1q; p.w_sc = w1s; p.out_q = mq; p.out_sc = ms; }
+    if (q) { p.comp = cmode; p.a_q = xq; p.a_sc = xs; p.w_q = w1q; p.w_sc = w1s; p.out_q = mq; p.out_sc = ms; }
     if (launch_gemm_f16(p, EPI_GELU_F16, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: fc1");
     GemmParams r{};
     r.tune = &h->tune; r.patches_per_img = 196; r.splitk_ws = ws; r.splitk_bytes = SKINNY_WS_BYTES;
     r.a_hi = mh; r.a_lo = ml; r.w_hi = w2h; r.w_lo = w2l; r.M = (int)M; r.N = (int)D; r.K = (int)F; r.nseg = lo ? 3 : 1; r.bias = fc2_b;
     r.ls = ls; r.resid = out;
-    if (q) { r.comp = 1; r.a_q = mq; r.a_sc = ms; r.w_q = w2q; r.w_sc = w2s; }
+    if (q) { r.comp = cmode; r.a_q = mq; r.a_sc = ms; r.w_q = w2q; r.w_sc = w2s; }
     if (launch_gemm_f16(r, EPI_RESID_LS, s) < 0) return h->fail(KEEP_EUNSUPPORTED, "op_mlp: fc2");
     HIPCHK(h, hipStreamSynchronize(s));
     return check_launch(h, "op_mlp");

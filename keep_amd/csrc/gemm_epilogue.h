@@ -70,91 +70,4 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, int m, in
     }
 }
 
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t orow, int prow, int n, f32x4 v) {
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += bias[e];
-    const int64_t o = orow * p.N + n;
-    if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
-        if (EPI == EPI_GELU_F16) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-        }
-        f16x4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { f16 hh, ll; split_f16(v[e], hh, ll); h[e] = hh; l[e] = ll; }
-        *reinterpret_cast<f16x4*>(p.out_hi + o) = h;
-        if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + o) = l;
-    } else if (EPI == EPI_RESID_LS) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls + n);
-        f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] += g[e] * v[e];
-        *reinterpret_cast<f32x4*>(p.resid + o) = r;
-    } else if (EPI == EPI_PATCH) {
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += pe[e];
-        *reinterpret_cast<f32x4*>(p.resid + o) = v;
-    } else {   // EPI_RESID_F32
-        const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += r[e];
-        *reinterpret_cast<f32x4*>(p.out_f32 + o) = v;
-    }
-}
-
-// Batched form: one output row m, NV column groups (4 consecutive n each).  Every global load the
-// epilogue needs (bias, LayerScale, residual / pos-embed rows) is issued BEFORE the first dependent
-// store, so a wave pays one memory round trip per row-batch instead of one per 16-byte group (the
-// compiler cannot hoist loads above the may-alias stores itself; that serialisation measured ~30 us
-// per 256x256 tile).
-template <int EPI, int NV>
-__device__ __forceinline__ void gemm_epilogue_batch(const GemmParams& p, int64_t orow, int prow, const int (&n)[NV], f32x4 (&v)[NV]) {
-    f32x4 bias[NV], aux[NV], res[NV];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        bias[q] = *reinterpret_cast<const f32x4*>(p.bias + n[q]);
-        if (EPI == EPI_RESID_LS) {
-            aux[q] = *reinterpret_cast<const f32x4*>(p.ls + n[q]);
-            res[q] = *reinterpret_cast<const f32x4*>(p.resid + orow * p.N + n[q]);
-        } else if (EPI == EPI_PATCH) {
-            res[q] = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n[q]);
-        } else if (EPI == EPI_RESID_F32) {
-            res[q] = *reinterpret_cast<const f32x4*>(p.resid + orow * p.N + n[q]);
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        const int64_t o = orow * p.N + n[q];
-        f32x4 x = v[q];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] += bias[q][e];
-        if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
-            if (EPI == EPI_GELU_F16) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = gelu_fast(x[e]);
-            }
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { f16 hh, ll; split_f16(x[e], hh, ll); h[e] = hh; l[e] = ll; }
-            *reinterpret_cast<f16x4*>(p.out_hi + o) = h;
-            if (p.out_lo) *reinterpret_cast<f16x4*>(p.out_lo + o) = l;
-        } else if (EPI == EPI_RESID_LS) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = res[q][e] + aux[q][e] * x[e];
-            *reinterpret_cast<f32x4*>(p.resid + o) = x;
-        } else if (EPI == EPI_PATCH) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += res[q][e];
-            *reinterpret_cast<f32x4*>(p.resid + o) = x;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] += res[q][e];
-            *reinterpret_cast<f32x4*>(p.out_f32 + o) = x;
-        }
-    }
-}
-
 }  // namespace keepk

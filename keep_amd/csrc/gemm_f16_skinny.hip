@@ -108,7 +108,7 @@ void gemm_skinny_reduce_kernel(GemmParams p, const float* __restrict__ part, int
         const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls + n);
         f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + o);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] += g[e] * v[e];
+        for (int e = 0; e < 4; ++e) r[e] += __fmul_rn(g[e], v[e]);     // LayerScale product rounded on its own, as the 256x256 kernel does: torch's x + gamma * y on every path
         *reinterpret_cast<f32x4*>(p.resid + o) = r;
     } else if (EPI == EPI_PATCH) {
         const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
@@ -146,7 +146,7 @@ void gemm_skinny_reduce_ln_kernel(GemmParams p, const float* __restrict__ part, 
         if (EPI == EPI_RESID_LS) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.ls + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] += g[e] * (v[e] + bias[e]);
+            for (int e = 0; e < 4; ++e) r[e] += __fmul_rn(g[e], v[e] + bias[e]);     // no fused multiply-add (same rounding as the 256x256 kernel's epilogue)
             *reinterpret_cast<f32x4*>(p.resid + o) = r;
         } else {
 #pragma unroll

@@ -16,7 +16,8 @@
 //     s_waitcnt vmcnt(G*(NSTAGE-2)) followed by a raw s_barrier (a __syncthreads() would drain the
 //     DMA queue to zero), and the DMA for tile s+NSTAGE-1 is issued right after that barrier
 //   * nseg == 3: hi/lo split product through the same accumulators (strict precision)
-//   * COMP: after the fp16 pass, the two first-order correction terms on the MX-fp4 pipe through the same accumulators (phase 2)
+//   * COMP = 2: after the fp16 pass, the two first-order correction terms on the MX-fp4 pipe through the same accumulators (phase 2);
+//     COMP = 1: the W_lo A_hi term only (half the MFMAs and DMA bytes of phase 2, and the producers of A skip the lo plane)
 //   * PERS: one workgroup per CU walks the tile sequence; the next tile's first three K steps are staged from the tail of the K loop
 //   * the K loop is written for its ISA: no branch but the back-edge, operand pointers carried from step to step, DMA addresses held in the
 //     scalar-base + 32-bit-lane-offset form (empty asm on the offsets), loops aligned to 64 B by the build -- every one of these was measured
@@ -72,10 +73,10 @@ constexpr int V2_PERS_LDS_F16 = 96 * 1024 + 8 * 4608;   // fp16 epilogues: one p
 // PERS ("persistent"): one workgroup per CU walks the tile sequence with stride gridDim.x and stages the first three K steps of its NEXT tile into the
 // ring stages that retire during the last steps of the current one, so they land while the epilogue runs (which then bounces through the
 // fourth stage and the 32 KiB of LDS behind the ring).  Same arithmetic, same tile order per XCD (tile t and t + 256 map to the same XCD).
-template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP = false, bool PERS = false>
+template <int BN, int WM, int WN, int NSTAGE, int EPI, int COMP = 0, bool PERS = false>
 __global__ __launch_bounds__(WM * WN * 64, v2_waves_per_simd(BN, WM, WN))
 void gemm_f16_v2_kernel(GemmParams p) {
-    static_assert(!PERS || (BN == 256 && NSTAGE == 4 && !COMP && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_RESID_LS)),
+    static_assert(!PERS || (BN == 256 && NSTAGE == 4 && COMP == 0 && (EPI == EPI_F16 || EPI == EPI_GELU_F16 || EPI == EPI_RESID_LS)),
                   "the persistent walk is written for the plain 256x256 / 4-stage kernel");
     constexpr int V2_THREADS = WM * WN * 64;
     constexpr int BM = V2_BM, BK = V2_BK;
@@ -173,7 +174,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
         const f16* ab = st_a;
         const f16* wb = st_w;
         st_a += 8192; st_w += 8192;
-        if (!(PERS || COMP) && --st_left == 0) {             // (persistent and compensated launches are single-pass: no segment boundary, no branch)
+        if (!(PERS || COMP != 0) && --st_left == 0) {             // (persistent and compensated launches are single-pass: no segment boundary, no branch)
             ++st_seg; st_left = ktiles;
             st_a = ((st_seg == 1) ? p.a_lo : p.a_hi) + a_tile + (int64_t)kt0 * 8192;
             st_w = ((st_seg == 2) ? p.w_lo : p.w_hi) + w_tile + (int64_t)kt0 * 8192;
@@ -283,10 +284,13 @@ void gemm_f16_v2_kernel(GemmParams p) {
     auto mfma_group = [&](const f16x8 (&fw)[TN], const f16x8 (&fa)[TM]) { mfma_head(fw, fa); mfma_tail(fw, fa); };
     // phase-2 (MX-fp4 correction terms, COMP only) operand stream; defined here because its first chunks are issued from the fp16 loop
     const unsigned char* aq = nullptr; const unsigned char* wq = nullptr; const unsigned char* sq = nullptr;
-    if constexpr (COMP) {
+    if constexpr (COMP != 0) {
         aq = p.a_q + (int64_t)(m0 >> 8) * KT * 8192;
         wq = p.w_q + (int64_t)(n0 >> 8) * KT * 8192;
-        sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512) + (wave & 3) * 256;     // wave-uniform; lanes add 4 * lane
+        // scales, wave-uniform (lanes add 4 * lane).  Two terms: a chunk is two 32-k blocks x two planes of 256 B per operand, wave & 3 = block * 2 + plane.
+        // One term: a chunk is four 32-k blocks of ONE plane (A: plane 0 = Q(A_hi), W: plane 1 = Q(W_lo)), wave & 3 = block.
+        if constexpr (COMP == 1) sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512 + 256) + (wave & 3) * 512;
+        else sq = (wave < 4 ? p.a_sc + (int64_t)(m0 >> 8) * KT * 512 : p.w_sc + (int64_t)(n0 >> 8) * KT * 512) + (wave & 3) * 256;
     }
     // stage2() is called for chunks 0, 1, 2, ... in order (the first three from the tail of the fp16 loop): running scalar bases, one unsigned
     // 32-bit lane offset per instruction kept opaque to the optimiser -- otherwise the addresses become 64-bit lane pointers (hoisted out of the
@@ -299,20 +303,22 @@ void gemm_f16_v2_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             // one opaque copy of the lane offset per instruction: a shared one gets added to the running base ONCE, as a 64-bit lane pointer
-            unsigned va = tid * 16, vw = tid * 16;
-            const unsigned char* ab = aq_run + r * 8192;
-            const unsigned char* wb = wq_run + r * 8192;
+            // two terms: round r = 32-k block r of the chunk, both planes (8 KiB contiguous per operand).  One term: the chunk covers K = 128; round r
+            // fetches plane 0 (A) / plane 1 (W) of blocks 2r (threads 0..255) and 2r + 1 (threads 256..511): 2 x 4 KiB pieces, the LDS image stays linear
+            unsigned va = COMP == 1 ? (tid >> 8) * 8192 + (tid & 255) * 16 : tid * 16, vw = COMP == 1 ? va + 4096 : va;
+            const unsigned char* ab = aq_run + r * (COMP == 1 ? 16384 : 8192);
+            const unsigned char* wb = wq_run + r * (COMP == 1 ? 16384 : 8192);
             asm volatile("" : "+v"(va), "+v"(vw), "+s"(ab), "+s"(wb));      // (and the scalar sums stay scalar)
             __builtin_amdgcn_global_load_lds((gptr_t)(ab + va), (lptr_t)(sb + (r * 512 + wave * 64) * 16), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(wb + vw), (lptr_t)(sb + 16384 + (r * 512 + wave * 64) * 16), 16, 0, 0);
         }
         __builtin_amdgcn_global_load_lds((gptr_t)(sq_run + v4), (lptr_t)(smem_raw + V2_SC2_BASE + buf * V2_SC2 + (wave >> 2) * 1024 + (wave & 3) * 256), 4, 0, 0);
-        aq_run += 16384; wq_run += 16384; sq_run += 1024;
+        aq_run += COMP == 1 ? 32768 : 16384; wq_run += COMP == 1 ? 32768 : 16384; sq_run += COMP == 1 ? 2048 : 1024;
     };
     // PRE: chunks 0..2 of phase 2 go out from the last fp16 steps, each into the phase-1 stage that step has just retired (chunk c lands in
     // stage c: the launcher admits compensated products only with a step count that is a multiple of the ring depth, K % 128 == 0, and
     // K >= 256) -- the fp4 phase then starts with its ring already full.
-    constexpr bool PRE = COMP && NSTAGE == V2_NST2;
+    constexpr bool PRE = COMP != 0 && NSTAGE == V2_NST2;
 #define KEEP_PIN() __builtin_amdgcn_sched_barrier(0)
 
 
@@ -424,11 +430,17 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // and term: 32 cycles per SIMD against 4 x 32 for the fp16 pass over the same K).  Per step a workgroup streams
     // 34 KiB (fp16 pass: 64 KiB per K = 64) through a 4-stage LDS-DMA ring laid over the fp16 ring's stages: 3 chunks in flight, counted vmcnt,
     // one raw barrier per chunk.
-    if constexpr (COMP) {
+    if constexpr (COMP != 0) {
         static_assert(BN == 256 && WM == 2 && WN == 4, "phase 2 is written for the 2 x 4 wave grid of the 256 x 256 tile");
         constexpr int G2 = V2_G2;
         if (p.dbg) t_first = __builtin_readcyclecounter();       // diagnostics: in a compensated launch stamp 1 marks the end of the fp16 phase
-        const int NC = p.K >> 6;
+        // One term (COMP == 1): the same loop -- 12 fragment reads, 4 scale dwords, 16 MFMAs, 5 DMA instructions and 34 KiB per chunk -- with a chunk
+        // covering K = 128 of the ONE product W_lo A_hi instead of K = 64 of two: half the chunks.  Per lane the two MFMAs of a tile then take the
+        // 32-k blocks fhi and 2 + fhi of the chunk (the LDS image holds the four blocks of one plane back to back: 4 KiB each).
+        constexpr int FH = COMP == 1 ? 4096 : 8192;              // LDS distance between the blocks of the two lane halves
+        constexpr int SEC = COMP == 1 ? 8192 : 4096;             // ... between a lane's first and second fragment set (one term: blocks fhi -> 2 + fhi; two: plane hi -> lo)
+        constexpr int SFH = COMP == 1 ? 256 : 512, SSEC = COMP == 1 ? 512 : 256;     // the same for the scale bytes
+        const int NC = COMP == 1 ? p.K >> 7 : p.K >> 6;
         if constexpr (PRE) {
             // chunks 0..2 are in flight since the last fp16 steps: one barrier both retires the phase-1 ring and publishes chunk 0
             wait_vmcnt<G2 * (V2_NST2 - 2)>();
@@ -444,7 +456,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
             __builtin_amdgcn_s_barrier();
         }
         const int a_row = (wm * 128 + frow) * 16, w_row = (wn * 64 + frow) * 16;
-        const int asc_off = fhi * 512 + (wm * 32 + frow) * 4, wsc_off = 1024 + fhi * 512 + ((wn >> 1) * 32 + frow) * 4;
+        const int asc_off = fhi * SFH + (wm * 32 + frow) * 4, wsc_off = 1024 + fhi * SFH + ((wn >> 1) * 32 + frow) * 4;
         const int wsh = (wn & 1) * 16;
         // One step per chunk: fetch the 12 fragments + 4 scale dwords, issue the DMA of chunk c+3, 16 MFMAs, counted wait, barrier.
         // The phase is bound by the LDS-DMA stream, like phase 1 (34 KiB per chunk against 64 KiB per K = 64 there, and it takes
@@ -452,30 +464,36 @@ void gemm_f16_v2_kernel(GemmParams p) {
         // barrier in between) measured 20 % SLOWER with or without sched_barrier pins, with the DMA issued early or late --
         // what counts is how long the DMA requests are in flight, and this order keeps three chunks outstanding the longest.
 #define KEEP_V8(V_) v8i{(int)(V_).x, (int)(V_).y, (int)(V_).z, (int)(V_).w, 0, 0, 0, 0}
+        // two terms: W_lo A_hi + W_hi A_lo (set "h" = plane hi, "l" = plane lo); one term: "h" / "l" are k 0..63 / 64..127 of the chunk, both of W_lo A_hi
 #define KEEP_MX(I, J) \
-            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah); \
-            acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal);
+            if constexpr (COMP == 1) { \
+                acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swh, J, sah); \
+                acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swl, J, sal); \
+            } else { \
+                acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wl[I]), KEEP_V8(ah[J]), acc[I][J], 4, 4, I, swl, J, sah); \
+                acc[I][J] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(KEEP_V8(wh[I]), KEEP_V8(al[J]), acc[I][J], 4, 4, I, swh, J, sal); \
+            }
         // One macro body, two loops (the last three chunks have nothing left to stage): the hot loop has no branch but its back-edge.
 #define KEEP_CHUNK(ISSUE, WAIT)                                                                                                    \
         {                                                                                                                          \
             const unsigned char* sb = smem_raw + (c & (V2_NST2 - 1)) * V2_ST2;                                                     \
             const unsigned char* ss = smem_raw + V2_SC2_BASE + (c & (V2_NST2 - 1)) * V2_SC2;                                       \
-            const unsigned char* sa = sb + fhi * 8192;      /* this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31 */            \
-            const unsigned char* sw = sb + 16384 + fhi * 8192;                                                                     \
+            const unsigned char* sa = sb + fhi * FH;        /* this lane's K slice of the chunk: k 32*fhi .. 32*fhi+31 (+ 64 .. in the one-term form) */ \
+            const unsigned char* sw = sb + 16384 + fhi * FH;                                                                       \
             /* native vector type, not HIP's uint4 struct: a struct load carries no alias info, and hipcc then puts an */          \
             /* s_waitcnt vmcnt(0) ("may read what an LDS-DMA in flight writes") in front of it: the ring drained on every chunk */  \
             u32x4 ah[4], al[4], wh[2], wl[2];                                                                                      \
             _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                                     \
                 ah[jj] = *reinterpret_cast<const u32x4*>(sa + a_row + jj * 512);                                                   \
-                al[jj] = *reinterpret_cast<const u32x4*>(sa + 4096 + a_row + jj * 512);                                            \
+                al[jj] = *reinterpret_cast<const u32x4*>(sa + SEC + a_row + jj * 512);                                             \
             }                                                                                                                      \
             _Pragma("unroll") for (int ii = 0; ii < 2; ++ii) {                                                                     \
                 wh[ii] = *reinterpret_cast<const u32x4*>(sw + w_row + ii * 512);                                                   \
-                wl[ii] = *reinterpret_cast<const u32x4*>(sw + 4096 + w_row + ii * 512);                                            \
+                wl[ii] = *reinterpret_cast<const u32x4*>(sw + SEC + w_row + ii * 512);                                             \
             }                                                                                                                      \
-            const int sah = *reinterpret_cast<const int*>(ss + asc_off), sal = *reinterpret_cast<const int*>(ss + asc_off + 256);  \
+            const int sah = *reinterpret_cast<const int*>(ss + asc_off), sal = *reinterpret_cast<const int*>(ss + asc_off + SSEC); \
             const int swh = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off) >> wsh),                                        \
-                      swl = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off + 256) >> wsh);                                  \
+                      swl = (int)(*reinterpret_cast<const unsigned*>(ss + wsc_off + SSEC) >> wsh);                                 \
             ISSUE;                                          /* into the stage chunk c-1 was read from */                           \
             KEEP_MX(0, 0) KEEP_MX(0, 1) KEEP_MX(0, 2) KEEP_MX(0, 3)                                                                \
             KEEP_MX(1, 0) KEEP_MX(1, 1) KEEP_MX(1, 2) KEEP_MX(1, 3)                                                                \
@@ -551,7 +569,8 @@ void gemm_f16_v2_kernel(GemmParams p) {
     static_assert(!PERS || (SLAB_BASE + SLAB_STRIDE * 4 * WM * WN <= V2_PERS_LDS && 32 * PITCH16 * 2 <= SLAB_STRIDE * 4), "persistent epilogue slabs must fit behind the three prefetched stages");
     float* slab = reinterpret_cast<float*>(smem_raw + SLAB_BASE) + wave * SLAB_STRIDE;
     auto slab_off = [&](int r, int col) { return PERS ? r * 64 + ((((col >> 2) + r) & 15) << 2) : r * PITCH + col; };   // col: multiple of 4
-    const bool want_lo = !PERS && (p.out_lo || p.out_q);
+    // (a one-term launch consumes and produces Q(X_hi) planes only: no lo slab, no lo quantisation, unless a caller asks for the fp16 lo plane itself)
+    const bool want_lo = !PERS && (p.out_lo || (p.out_q && COMP != 1));
     constexpr bool F16_OUT = (EPI == EPI_F16 || EPI == EPI_GELU_F16);
     constexpr int CPL = F16_OUT ? 8 : 4;             // columns per lane on the way out
     constexpr int LPR = WN_COLS / CPL;               // lanes per row
@@ -614,7 +633,7 @@ void gemm_f16_v2_kernel(GemmParams p) {
                     f32x2 b = {acc[i][j][rg * 4 + 2] + bfrag[i * 4 + rg][2], acc[i][j][rg * 4 + 3] + bfrag[i * 4 + rg][3]};
                     if (EPI == EPI_GELU_F16) {
                         // strict / compensated (lo or fp4 planes wanted): full-accuracy polynomial; a persistent launch is hi-only by construction
-                        if (COMP || (!PERS && (p.out_lo || p.out_q))) { a = gelu_fast2(a); b = gelu_fast2(b); }     // (a compensated launch always is)
+                        if (COMP != 0 || (!PERS && (p.out_lo || p.out_q))) { a = gelu_fast2(a); b = gelu_fast2(b); }     // (a compensated launch always is)
                         else { a = gelu_fast2_fp16(a); b = gelu_fast2_fp16(b); }
                     }
                     f16x4 h, l;
@@ -640,6 +659,8 @@ void gemm_f16_v2_kernel(GemmParams p) {
                         if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + o) = l;
                         // this GEMM's N is the consumer's K: 8 lanes cover the wave's 64 columns = two MX blocks of 4 lanes each
                         if (p.out_q) q4_store8(p.out_q, p.out_sc, p.out_kt, m, ncol >> 5, (ocol >> 3) & 3, h, l);
+                    } else if (COMP == 1 && !PERS && p.out_q) {
+                        q4_store8_hi(p.out_q, p.out_sc, p.out_kt, m, ncol >> 5, (ocol >> 3) & 3, h);
                     }
                 }
             }
@@ -695,49 +716,25 @@ void gemm_f16_v2_kernel(GemmParams p) {
     }
 }
 
-// hipFuncSetAttribute is per device: remember per kernel instantiation which devices have been opted in
-template <class K>
-bool v2_opt_in_lds(K kernel, size_t bytes) {
-    static unsigned long long done = 0;              // bit d: device d
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (dev < 64 && (done >> dev) & 1ull) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    if (dev < 64) done |= 1ull << dev;
-    return true;
-}
-
-// number of CUs of the current device (the persistent kernel's grid)
-static int v2_num_cus() {
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev >= 64) return 256;
-    if (!cus[dev]) {
-        int n = 0;
-        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return cus[dev];
-}
-
 template <int EPI>
 int launch_v2_pers(const GemmParams& p, hipStream_t s) {
-    auto kernel = &gemm_f16_v2_kernel<256, 2, 4, 4, EPI, false, true>;
+    auto kernel = &gemm_f16_v2_kernel<256, 2, 4, 4, EPI, 0, true>;
     constexpr size_t lds_bytes = (EPI == EPI_F16 || EPI == EPI_GELU_F16) ? V2_PERS_LDS_F16 : V2_PERS_LDS;
-    if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
+    if (!keep_lds_opt_in(reinterpret_cast<const void*>(kernel), lds_bytes)) return -2;
     const int tiles = (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM);
-    int cus = v2_num_cus();
+    int cus = keep_num_cus();
     if (p.tune && p.tune->gemm_persistent > 1 && p.tune->gemm_persistent < cus) cus = p.tune->gemm_persistent;     // experiment: fewer workgroups than CUs
     hipLaunchKernelGGL(kernel, dim3(tiles < cus ? tiles : cus), dim3(512), lds_bytes, s, p);
     return 0;
 }
 
-template <int BN, int WM, int WN, int NSTAGE, int EPI, bool COMP>
+template <int BN, int WM, int WN, int NSTAGE, int EPI, int COMP>
 int launch_v2_one(const GemmParams& p, hipStream_t s) {
     constexpr size_t ring = (size_t)NSTAGE * (V2_BM + BN) * V2_BK * sizeof(f16);
     constexpr size_t ring2 = (size_t)V2_NST2 * (V2_ST2 + V2_SC2);
-    constexpr size_t lds_bytes = COMP && ring2 > ring ? ring2 : ring;
+    constexpr size_t lds_bytes = COMP != 0 && ring2 > ring ? ring2 : ring;
     auto kernel = &gemm_f16_v2_kernel<BN, WM, WN, NSTAGE, EPI, COMP>;
-    if (!v2_opt_in_lds(kernel, lds_bytes)) return -2;
+    if (!keep_lds_opt_in(reinterpret_cast<const void*>(kernel), lds_bytes)) return -2;
     const int grid = (p.N / BN) * ((p.M + V2_BM - 1) / V2_BM) * (EPI == EPI_PARTIAL ? p.ksplit : 1);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(WM * WN * 64), lds_bytes, s, p);
     return 0;
@@ -746,12 +743,12 @@ int launch_v2_one(const GemmParams& p, hipStream_t s) {
 template <int BN, int WM, int WN, int NSTAGE>
 int launch_v2(const GemmParams& p, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_F16:      return launch_v2_one<BN, WM, WN, NSTAGE, EPI_F16, false>(p, s);
-        case EPI_GELU_F16: return launch_v2_one<BN, WM, WN, NSTAGE, EPI_GELU_F16, false>(p, s);
-        case EPI_RESID_LS: return launch_v2_one<BN, WM, WN, NSTAGE, EPI_RESID_LS, false>(p, s);
-        case EPI_PATCH:    return launch_v2_one<BN, WM, WN, NSTAGE, EPI_PATCH, false>(p, s);
-        case EPI_PARTIAL:  return launch_v2_one<BN, WM, WN, NSTAGE, EPI_PARTIAL, false>(p, s);
-        default:           return launch_v2_one<BN, WM, WN, NSTAGE, EPI_RESID_F32, false>(p, s);
+        case EPI_F16:      return launch_v2_one<BN, WM, WN, NSTAGE, EPI_F16, 0>(p, s);
+        case EPI_GELU_F16: return launch_v2_one<BN, WM, WN, NSTAGE, EPI_GELU_F16, 0>(p, s);
+        case EPI_RESID_LS: return launch_v2_one<BN, WM, WN, NSTAGE, EPI_RESID_LS, 0>(p, s);
+        case EPI_PATCH:    return launch_v2_one<BN, WM, WN, NSTAGE, EPI_PATCH, 0>(p, s);
+        case EPI_PARTIAL:  return launch_v2_one<BN, WM, WN, NSTAGE, EPI_PARTIAL, 0>(p, s);
+        default:           return launch_v2_one<BN, WM, WN, NSTAGE, EPI_RESID_F32, 0>(p, s);
     }
 }
 
@@ -766,15 +763,22 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
     if (p.K % V2_BK) return 1;
     if (p.comp) {
         if (p.N % 256 || p.K % 128 || p.K < 256 || p.nseg != 1 || !p.a_q || !p.a_sc || !p.w_q || !p.w_sc) return 1;
-        if (epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, true>(p, s);
-        if (epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, true>(p, s);
-        if (epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, true>(p, s);
-        if (epi == EPI_TOP2) return launch_v2_one<256, 2, 4, 4, EPI_TOP2, true>(p, s);
+        if (p.comp == 1) {                               // the W_lo term only: chunks of K = 128, at least four of them (image-tower MLP shapes)
+            if (p.K < 512) return 1;
+            if (epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, 1>(p, s);
+            if (epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, 1>(p, s);
+            if (epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, 1>(p, s);
+            return 1;
+        }
+        if (epi == EPI_GELU_F16) return launch_v2_one<256, 2, 4, 4, EPI_GELU_F16, 2>(p, s);
+        if (epi == EPI_RESID_LS) return launch_v2_one<256, 2, 4, 4, EPI_RESID_LS, 2>(p, s);
+        if (epi == EPI_F16) return launch_v2_one<256, 2, 4, 4, EPI_F16, 2>(p, s);
+        if (epi == EPI_TOP2) return launch_v2_one<256, 2, 4, 4, EPI_TOP2, 2>(p, s);
         return 1;
     }
-    if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, false>(p, s);
+    if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, 0>(p, s);
     if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
-        (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > v2_num_cus()) {
+        (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > keep_num_cus()) {
         // (a device that does not grant all 160 KiB of LDS to one workgroup falls through to the one-tile-per-workgroup launch)
         if (epi == EPI_F16 && launch_v2_pers<EPI_F16>(p, s) == 0) return 0;
         if (epi == EPI_GELU_F16 && launch_v2_pers<EPI_GELU_F16>(p, s) == 0) return 0;

@@ -71,4 +71,12 @@ __device__ __forceinline__ void q4_store8(unsigned char* q, unsigned char* sc, i
     if (quarter == 1) sc[q4_scale_off(row, kt, 1, KT)] = (unsigned char)el;
 }
 
+// The same for the hi plane alone (one-term compensation: the consumer reads Q(X_hi) only; the lo plane of the block is left untouched).
+__device__ __forceinline__ void q4_store8_hi(unsigned char* q, unsigned char* sc, int KT, int row, int kt, int quarter, const f16x8& hi) {
+    unsigned eh;
+    const unsigned wh = q4_quantize8(hi, eh);
+    *reinterpret_cast<unsigned*>(q + q4_data_off(row, kt, 0, KT) + quarter * 4) = wh;
+    if (quarter == 0) sc[q4_scale_off(row, kt, 0, KT)] = (unsigned char)eh;
+}
+
 }  // namespace keepk

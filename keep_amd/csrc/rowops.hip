@@ -113,7 +113,7 @@ void layernorm_blk_kernel(LnParams p) {
             }
             if (p.out_f32 && row < p.rows) *reinterpret_cast<f32x4*>(p.out_f32 + (int64_t)row * p.out_f32_stride + col) = y;
             *reinterpret_cast<f16x4*>(s_hi + lr * PITCH + col) = h;
-            if (p.out_lo || p.out_q) *reinterpret_cast<f16x4*>(s_lo + lr * PITCH + col) = l;
+            if (p.out_lo || (p.out_q && !p.out_q_hi_only)) *reinterpret_cast<f16x4*>(s_lo + lr * PITCH + col) = l;
         }
     }
     __syncthreads();
@@ -126,11 +126,13 @@ void layernorm_blk_kernel(LnParams p) {
             const int64_t dst = blk_off(row, kt * 32 + ochunk, KT);
             const f16x8 h8 = *reinterpret_cast<const f16x8*>(s_hi + orow * PITCH + kt * 32 + ochunk);
             *reinterpret_cast<f16x8*>(p.out_hi + dst) = h8;
-            if (p.out_lo || p.out_q) {
+            if (p.out_lo || (p.out_q && !p.out_q_hi_only)) {
                 const f16x8 l8 = *reinterpret_cast<const f16x8*>(s_lo + orow * PITCH + kt * 32 + ochunk);
                 if (p.out_lo) *reinterpret_cast<f16x8*>(p.out_lo + dst) = l8;
                 // the four lanes lane&~3 .. lane|3 hold the four quarters of this (row, K slice): one MX block
                 if (p.out_q) q4_store8(p.out_q, p.out_sc, KT, row, kt, lane & 3, h8, l8);
+            } else if (p.out_q) {
+                q4_store8_hi(p.out_q, p.out_sc, KT, row, kt, lane & 3, h8);          // one-term compensation downstream: Q(x_hi) only
             }
         }
     }
@@ -508,7 +510,7 @@ int launch_layernorm(const LnParams& p, hipStream_t s) {
     if (p.out_q && !blk_ok) return -1;                  // the fp4 planes are only produced by the blk-layout kernel
     if ((ln_impl == 1 || p.out_q) && blk_ok) {
         constexpr int R = 8;
-        const size_t lds = (size_t)R * (p.D + 32) * 2 * ((p.out_lo || p.out_q) ? 2 : 1);
+        const size_t lds = (size_t)R * (p.D + 32) * 2 * ((p.out_lo || (p.out_q && !p.out_q_hi_only)) ? 2 : 1);
         dim3 g((p.rows + R - 1) / R), b(R * 64);
         if (p.D == 1024) hipLaunchKernelGGL((layernorm_blk_kernel<4, R>), g, b, lds, s, p);
         else hipLaunchKernelGGL((layernorm_blk_kernel<3, R>), g, b, lds, s, p);

@@ -62,15 +62,17 @@ class TextEmbeddingCache:
 # the same KEEP_model dict (zeroshot_subtyping_WSI.py:59-62), so repeated strings are embedded once without any change to the call site.
 # The cache lives ON the model object (and refers back to it weakly): it goes away with the model, and nothing global pins a model.
 PROMPT_CACHE = True          # False: embed every string on every call, exactly as the reference does
+TEXT_OPTIONS = ("precision", "strict_blocks")      # the engine options encode_text depends on
 
 
 def _cache_for(KEEP_model, device) -> TextEmbeddingCache:
     m, tok = KEEP_model["model"], KEEP_model["tokenizer"]
     if not PROMPT_CACHE or not isinstance(m, KEEPModel):
         return TextEmbeddingCache(KEEP_model, device)
-    # embeddings depend on the weights and on the precision setting of the text tower: set_precision / set_option after the first call
-    # must not return embeddings computed under the old setting
-    key = (id(tok), getattr(m, "_weights_epoch", 0), str(device), tuple(sorted((k, float(v)) for k, v in m._options.items())))
+    # embeddings depend on the weights and on the precision setting of the TEXT tower (precision, strict_blocks): set_precision after the first
+    # call must not return embeddings computed under the old setting.  Image-only options (the per-block plan, lanes, kernel selection) do not
+    # touch the text tower and leave the cache alone.
+    key = (id(tok), getattr(m, "_weights_epoch", 0), str(device), tuple((k, float(m._options.get(k, 0))) for k in TEXT_OPTIONS))
     slot = getattr(m, "_prompt_cache", None)
     if slot is None or slot[0] != key:
         slot = (key, TextEmbeddingCache(KEEP_model, device, weak=True))
@@ -79,12 +81,17 @@ def _cache_for(KEEP_model, device) -> TextEmbeddingCache:
 
 
 def _unit_rows(m: KEEPModel, x: torch.Tensor) -> torch.Tensor:
-    """Rows of a 2-D fp32 tensor divided by max(||row||, 1e-12) on the engine (``F.normalize(x, dim=-1)`` semantics; keep_op_l2norm) --
-    torch holds the storage, the arithmetic is the engine's row kernel."""
-    dev = x.device
+    """Rows of a 2-D tensor divided by max(||row||, 1e-12) on the engine (``F.normalize(x, dim=-1)`` semantics; keep_op_l2norm) --
+    torch holds the storage, the arithmetic is the engine's fp32 row kernel; the result comes back in the dtype and on the device of ``x``
+    (the reference's ``F.normalize`` keeps both).  There is deliberately no torch fallback: with a text encoder that is not a ``KEEPModel``
+    the normalisation still runs on the engine of the device (a weight-less handle: these kernels need no weights), and without a GPU the
+    call raises like every other entry point of this package."""
+    dev, dt = x.device, x.dtype
     r = x.detach().to(m._device, torch.float32).contiguous().clone()
     if r.numel():
         _lib.check(m._handle, _lib.load().keep_op_l2norm(m._handle, _ptr(r), r.shape[0], r.shape[1], _stream(m._device)), "l2norm")
+    if dt.is_floating_point and dt != torch.float32:
+        r = r.to(dt)
     return r if dev == m._device else r.to(dev)
 
 

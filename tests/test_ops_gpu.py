@@ -125,6 +125,41 @@ def test_compensated_linear_recovers_the_fp16_rounding(ops, M, N, K, epi):
     assert (e_comp[Mb:] .max() if Mb < M else torch.tensor(0.)) < 4 * e_fp16.max()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1000, 1024, 1024, EPI_F16), (394, 4096, 1024, EPI_GELU_F16), (2048, 1024, 4096, EPI_RESID_LS),
+                                       (257, 256, 512, EPI_F16), (300, 768, 3072, EPI_RESID_LS)])
+def test_one_term_compensated_linear_removes_the_weight_rounding(ops, M, N, K, epi):
+    """split=3 (KEEP_MLP_COMP_W's GEMM): A_hi W_hi on the fp16 pipe + Q4(A_hi) Q4(W_lo) on the MX-fp4 pipe, K = 128 per chunk.  What it must
+    deliver is the product of the fp16-ROUNDED activations with the UNROUNDED weights: against that reference the error has to be a small
+    fraction of the weight-rounding error it removes, on every 32 x 32 patch (a wrong plane, block order or scale byte adds error instead);
+    against the exact product it keeps the activation half of the fp16 rounding error -- no more, no less."""
+    a, w, b = rand(M, K, seed=51), rand(N, K, seed=52, std=0.04), rand(N, seed=53, std=0.1)
+    ls = torch.rand(N, generator=torch.Generator().manual_seed(54)) * 0.45 + 0.05
+    resid = rand(M, N, seed=55)
+    kw = dict(ls=ls, resid=resid) if epi == EPI_RESID_LS else {}
+    fin = {EPI_GELU_F16: gelu64, EPI_RESID_LS: lambda acc: resid.double() + ls.double() * acc}.get(epi, lambda acc: acc)
+    ref = fin(a.double() @ w.double().t() + b.double())                    # exact
+    ref_w = fin(r16(a) @ w.double().t() + b.double())                      # activations rounded, weights exact: the one-term target
+    ref16 = fin(r16(a) @ r16(w).t() + b.double())                          # both rounded: the plain fp16 product
+    out = ops.linear(a, w, b, epi, 3, **kw).cpu().double()
+    rms = lambda e: e.pow(2).mean().sqrt().item()
+    e_t, w_err, e_x, e16 = out - ref_w, ref16 - ref_w, out - ref, ref16 - ref
+    print(f"[one-term linear {M}x{N}x{K} epi{epi}] vs A_hi W: rms {rms(e_t):.3e} (weight-rounding error it removes: {rms(w_err):.3e}); "
+          f"vs exact: {rms(e_x):.3e} (plain fp16 product {rms(e16):.3e})")
+    out_round = 0.0 if epi == EPI_RESID_LS else rms(ref_w) * 2.0 ** -12   # an fp16 output cannot be closer than its own rounding
+    assert rms(e_t) < 0.3 * rms(w_err) + 1.5 * out_round
+    assert 0.5 * rms(e16) < rms(e_x) + out_round and rms(e_x) < 0.9 * rms(e16) + 1.5 * out_round
+    if epi == EPI_RESID_LS:
+        Mb, Nb = M // 32 * 32, N // 32 * 32
+        blk = lambda e: e[:Mb, :Nb].reshape(Mb // 32, 32, Nb // 32, 32).pow(2).mean(dim=(1, 3)).sqrt()
+        assert (blk(e_t) < 0.6 * blk(w_err).clamp_min(1e-12)).all()
+
+
+@pytest.mark.parametrize("K", [256, 384, 448])
+def test_one_term_compensated_linear_needs_four_chunks_of_128(ops, K):
+    with pytest.raises(ValueError, match="K%128"):
+        ops.linear(rand(256, K, seed=1), rand(256, K, seed=2), torch.zeros(256), EPI_F16, 3)
+
+
 @pytest.mark.parametrize("K", [64, 192, 320])
 def test_compensated_linear_rejects_k_that_does_not_fill_the_ring(ops, K):
     """The fp4 phase's first chunks are staged into the fp16 ring's stages as they retire: K must be a multiple of 4 K steps (128)
@@ -163,12 +198,14 @@ def test_mlp_block_modes(ops, D, F, M):
     h = torch.nn.functional.layer_norm(xd, (D,), ln_w.double(), ln_b.double(), 1e-6)
     ref = xd + ls.double() * (gelu64(h @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
     err = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         out = ops.mlp(x, ln_w, ln_b, w1, b1, w2, b2, ls, mode).cpu().double()
         err[mode] = (out - ref).pow(2).mean().sqrt().item()
-    print(f"[mlp D{D} M{M}] rms err: fp16 {err[0]:.3e}  split {err[1]:.3e}  compensated {err[2]:.3e}")
+    print(f"[mlp D{D} M{M}] rms err: fp16 {err[0]:.3e}  split {err[1]:.3e}  compensated {err[2]:.3e}  compensated, W_lo term only {err[3]:.3e}")
     assert err[1] < 0.05 * err[0]
     assert err[2] < 0.25 * err[0]
+    # mode 3 (LayerNorm and the GELU epilogue write Q(x_hi) only; both GEMMs add Q4(A_hi) Q4(W_lo)): the weight half of the rounding variance goes
+    assert err[2] < err[3] < 0.85 * err[0] and err[3] > 0.55 * err[0]
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(16640, 1024, 1024, EPI_RESID_LS), (8300, 3072, 1024, EPI_F16), (9000, 4096, 1024, EPI_GELU_F16),

@@ -36,6 +36,9 @@ def test_image_tower_matches_golden(golden_dir, depth):
     # pin 2: timm's module tree on the ATen ops timm dispatches (tools/make_golden.py `_TimmViT`), loaded strictly from the release key layout
     assert np.abs(feat.numpy() - g["features_aten_timm"]).max() < 1e-6
     assert float(g["pins_dfeat"]) < 1e-6 and float(g["oracle_dfeat_aten_timm"]) < 1e-6
+    # pin 3, present once tools/pin_against_timm.py has run somewhere timm is installed: timm's own vit_large_patch16_224 built as the reference does
+    if "features_timm" in g.files:
+        assert np.abs(feat.numpy() - g["features_timm"]).max() < 1e-6
     assert np.allclose(np.linalg.norm(feat.numpy(), axis=1), 1.0, atol=1e-6)
 
 

@@ -23,15 +23,22 @@ from keep_amd.synth import synth_state_dict                               # noqa
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiles", type=int, default=100_000)
-    ap.add_argument("--settings", nargs="*", default=["1,6", "1,8", "1,10"])
+    ap.add_argument("--settings", nargs="*", default=["1,8", "1,10"], help="extra prefix plans (comp_full_blocks,comp_mlp_blocks) measured on the first slide")
+    ap.add_argument("--seeds", type=int, default=5, help="number of synthetic slides (tile seeds 1000, 2000, ...)")
+    ap.add_argument("--family", default="default", help="weight family of keep_amd.synth (default | heavy_tail | small_ls)")
+    ap.add_argument("--budget", default="ladder", choices=["ladder", "measured"])
     ap.add_argument("--out", default="gpurun_out/c4_parity.json")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = KEEPModel(KEEPShape())
-    model.load_state_dict(synth_state_dict(KEEPShape(), seed=0))
+    model.load_state_dict(synth_state_dict(KEEPShape(), seed=0, family=args.family))
     model.to(dev).eval()                                                  # calibrates: `headline_setting` below is what load_state_dict picked
+    if args.budget != "ladder":
+        model.calibrate(budget=args.budget)
     model.reserve(tiles=256)
-    res = bench.config4(model, dev, n=args.tiles, settings=[tuple(int(v) for v in st.split(",")) for st in args.settings])
+    res = bench.config4(model, dev, n=args.tiles, settings=[tuple(int(v) for v in st.split(",")) for st in args.settings],
+                        seeds=tuple(1000 * (i + 1) for i in range(args.seeds)))
+    res["weight_family"] = args.family
     res["calibration"] = model.calibration
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(res, open(args.out, "w"), indent=1)

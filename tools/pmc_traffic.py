@@ -21,8 +21,10 @@ write = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
 TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>",
         "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, true>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>",
         "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "vit.attn": "attention_pers_kernel<13>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
-# algorithmic bytes per launch of one 128-tile lane (M = 25 216 rows): operands read once + outputs written once (+ fp32 residual read-modify-write)
-M = 128 * 197
+# algorithmic bytes per launch of TILES tiles (argv[4], default 128 = one lane of the two-lane bench; 256 when the passes ran with --opt streams=1):
+# operands read once + outputs written once (+ fp32 residual read-modify-write)
+TILES = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+M = TILES * 197
 ALGO = {"vit.fc1": 2 * (M * 1024 + 4096 * 1024) + 2 * M * 4096, "vit.qkv": 2 * (M * 1024 + 3072 * 1024) + 2 * M * 3072,
         "vit.attn": 2 * M * 3072 + 2 * M * 1024, "vit.ln": 4 * M * 1024 + 2 * M * 1024}
 # the fp32-residual kernel is launched for proj (K = 1024) and fc2 (K = 4096): as many fc2 launches as plain fc1 launches, the rest are proj
@@ -38,7 +40,7 @@ for tag, pat in TAGS.items():
     w = [(v, n) for k, (v, n) in write.items() if pat in k]
     if f and w:
         out[tag] = {"kernel": pat, "fetch_kib_raw": round(f[0][0], 1), "write_kib": round(w[0][0], 1), "dispatches": f[0][1],
-                    "bytes_per_launch": round((2 * f[0][0] + w[0][0]) * 1024)}
+                    "bytes_per_launch": round((2 * f[0][0] + w[0][0]) * 1024), "tiles_per_launch": TILES}
         if tag in ALGO:
             out[tag]["algorithmic_bytes_per_launch"] = ALGO[tag]
             out[tag]["traffic_over_algorithmic"] = round(out[tag]["bytes_per_launch"] / ALGO[tag], 2)

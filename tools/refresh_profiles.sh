@@ -19,9 +19,10 @@ cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 rocprofv3 --kernel-trace --stats -d /tmp/kt1 --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 $LEAN --no-breakdown --opt streams=1 $SET \
     > "$OUT/bench_single_stream_under_rocprofv3.json" 2> "$OUT/kt1.log"
 cp "$(find /tmp/kt1 -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_single_stream.csv"
-# 3. counters: their own passes, kernel-trace only (FETCH_SIZE and WRITE_SIZE do not share a pass)
+# 3. counters: their own passes, kernel-trace only (FETCH_SIZE and WRITE_SIZE do not share a pass); one internal stream, so a launch is 256 tiles --
+#    the same launch bench.py's roofline.flops_per_launch / avg_launch_ms describe
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 $LEAN --no-breakdown $SET \
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 $LEAN --no-breakdown --opt streams=1 $SET \
       > /dev/null 2> "$OUT/pmc_$c.log"
 done
 # 4. matrix-pipe utilisation and clock, two lanes and one stream (clean per-kernel attribution) -> the per-kernel table
@@ -33,7 +34,7 @@ cd "$REPO"
 python tools/pmc_summary.py "$(find /tmp/pmc_MFMA -name '*counter_collection.csv' | head -1)" > "$OUT/mfma_busy.txt" 2>&1
 sha256sum keep_amd/libkeep_hip.so | cut -c1-16 > "$OUT/lib_sha16.txt"
 python tools/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" \
-                            "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" > /dev/null
+                            "$(find /tmp/pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)" "$OUT/hbm_traffic.json" 256 > /dev/null
 head -1 "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_csv_header.txt"
 # the raw single-stream counter CSV travels back too (a few MB), so that tools/kernel_table.py can be re-run off the box
 gzip -c "$(find /tmp/pmc_MFMA1 -name '*counter_collection.csv' | head -1)" > "$OUT/pmc_mfma_single_stream_counter_collection.csv.gz"
