@@ -152,13 +152,17 @@ void attention_kernel(AttnParams p) {
     // Addresses are a wave-uniform base plus ONE 32-bit lane offset (the launcher refuses buffers of 2^31 elements or more): 64-bit lane
     // addresses for the Q loads and the output stores were loop invariants the compiler hoisted, ran out of registers on (128 per wave at
     // this occupancy) and spilled -- every output store of every query tile then sat behind a scratch reload and an s_waitcnt vmcnt(0).
+    // (p.q_hi: the single query row of this image lives in a compact [batch][q_ld] buffer -- every lane of the one query tile then reads that row;
+    // only row 0 is stored, q_rows == 1)
+    const f16* q_base = (!SPLIT && p.q_hi) ? p.q_hi + (int64_t)b * p.q_ld : base_hi;
+    const unsigned q_stride = (!SPLIT && p.q_hi) ? 0u : (unsigned)D3;
     auto load_q = [&](int qt) {
         int q = qt * 16 + qi;
         q = q < ntok ? q : ntok - 1;
-        const unsigned qo = (unsigned)q * (unsigned)D3 + (unsigned)(h * HD + g * 8);
+        const unsigned qo = (unsigned)q * q_stride + (unsigned)(h * HD + g * 8);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qn[ks] = *reinterpret_cast<const f16x8*>(base_hi + (qo + ks * 32));
+            qn[ks] = *reinterpret_cast<const f16x8*>(q_base + (qo + ks * 32));
             if (SPLIT) qln[ks] = *reinterpret_cast<const f16x8*>(base_lo + (qo + ks * 32));
         }
     };
@@ -528,6 +532,7 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
 #endif
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
+    if (p.q_hi && (p.q_rows != 1 || p.split)) return -1;          // the compact query buffer holds one row per image, single-pass only
     // 32-bit lane offsets inside the kernel: qkv rows of one (batch) slice and the whole output plane (padded to 256 rows) stay below 2^31 elements
     if ((int64_t)p.ntok * 3 * p.heads * HD >= (1ll << 31) || ((int64_t)p.batch * p.ntok + 255) / 256 * 256 * p.heads * HD >= (1ll << 31)) return -1;
     if (p.split) {

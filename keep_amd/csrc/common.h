@@ -115,12 +115,16 @@ struct GemmParams {
     float* out_f32;                       // EPI_RESID_F32
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
     int out_kt;                           // > 0: fp16 output in blk layout with KT = out_kt (= N/32); 0: row-major [M][N]
+    int out_ld, out_col0;                 // row-major fp16 output (EPI_F16, 256x256 kernel only): leading dimension (0 = N) and first column of this GEMM's N columns
+                                          // inside a wider buffer (the K | V part of the last block's qkv)
     int patches_per_img;                  // EPI_PATCH: 196
     // optional LayerNorm of the updated row, fused into the split-K reduce (EPI_RESID_LS / EPI_RESID_F32, N <= 1024);
     // launch_gemm_f16 reports through its return value whether it was applied (bit 0) -- the big kernel never does
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     f16* ln_out_hi; f16* ln_out_lo; float* ln_out_f32;   // fp16 in blk layout (KT = N / 32); fp32 row-major [M][N], may alias resid / out_f32
     int top2_c; float* top2_partial; int top2_kpad;   // EPI_TOP2: classes per classifier, [2 * ceil(M/256)][top2_kpad] partial sums
+    int impl_hint;                        // per-call kernel choice of the caller (engine option "proj_impl"): 2128 = 256x128 tiles, 4 waves, 3-stage ring, TWO
+                                          // workgroups per CU (72 KiB of LDS each) -- one workgroup's epilogue runs under the other's K loop; 0 = the default choice
     int ksplit;                           // internal (EPI_PARTIAL): number of K slices the grid is replicated over
     float* splitk_ws; size_t splitk_bytes; // scratch for the small-M split-K kernel (gemm_f16_skinny.hip); null: never used
     long long* dbg;                       // diagnostics: per-workgroup [start, first tile landed, loop end, end] shader clocks
@@ -145,6 +149,8 @@ struct AttnParams {
     const int64_t* mask;                  // [batch][ntok] (1 = attend) or nullptr
     int batch, ntok, heads;               // head_dim fixed at 64
     int q_rows;                           // > 0: only the first q_rows query rows of every image are computed (CLS-only last block)
+    const f16* q_hi; int q_ld;            // q_rows == 1 only, nullable: the ONE query row of image b at q_hi + b * q_ld (head-major, like the q part of a qkv row) instead of
+                                          // qkv_hi -- the last block computes Q for its CLS rows only
     int split;                            // 0/1
     float scale;                          // 1/sqrt(64)
     long long* dbg;                       // diagnostics: per-workgroup [start, staged, end] shader clocks (tools/attn_timeline.py)

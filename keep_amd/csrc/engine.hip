@@ -129,6 +129,8 @@ struct keep_handle {
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
+    int cls_qkv = 1;             // last ViT block (with cls_tail): the q part of the qkv GEMM for the CLS rows only (exact; 0 = all rows)
+    int proj_impl = 0;           // 2128: the plain proj GEMMs of the image tower on the 256x128 / two-workgroups-per-CU kernel (GemmParams.impl_hint); 0: the persistent 256x256 kernel
     // hipGraph replay of launch-bound calls (one prompt / one tile: ~100 dependent kernels of a few us each)
     struct GraphSlot { hipGraphExec_t exec; unsigned long long epoch; char* arena; };
     std::map<std::string, GraphSlot> graphs;
@@ -465,13 +467,26 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
     }
     L.xn_ready = false;
+    // Last block, single-pass lanes: only the CLS row of every image is a query, so the q third of the qkv GEMM is computed for those Bc rows only
+    // (exact: the skipped rows' q is never read; the FLOPs it saves are not counted as done).  K and V still need every token.
+    const bool kv_only = cls_only && h->cls_qkv && !sp && !qkv_q && Bc >= 32 && !L.xn_ready && D % 256 == 0;
     {
         const int tag = (sp || qkv_q) ? T_VIT_QKV_X : T_VIT_QKV;
         Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, b.qkv_b);
+        if (kv_only) {          // weight rows D .. 3D-1 (n-tiles D/256 ..), written into columns D .. 3D-1 of the token-major qkv buffer
+            p.N = 2 * D; p.w_hi += (int64_t)(D / 256) * (D / 32) * 8192; p.bias += D; p.out_ld = 3 * D; p.out_col0 = D;
+        }
         p.out_hi = ws.qkv_hi; p.out_lo = sp ? ws.qkv_lo : nullptr;
         if (qkv_q) { p.comp = 2; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.qkv->q; p.w_sc = b.qkv->sc; }
         if (run_gemm(h, tag, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "qkv GEMM launch failed");
+    }
+    if (kv_only) {              // q of the CLS rows: gather their LayerNorm-1 rows, [Bc, D] x W_q^T on the small-M kernel, into a compact buffer (free until the MLP)
+        Scope sc(h, T_VIT_TAIL, s);
+        launch_gather_rows_blk(ws.xn_hi, 197, ws.c_xn_hi, Bc, D, s);
+        GemmParams p = gemm_params(h, ws.c_xn_hi, nullptr, b.qkv, Bc, false, b.qkv_b);
+        p.N = D; p.out_hi = ws.c_mlp_hi;
+        if (run_gemm(h, T_VIT_TAIL, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-query GEMM launch failed");
     }
     mark(1);
     {
@@ -481,6 +496,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
         a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
         a.q_rows = cls_only ? 1 : 0;
+        if (kv_only) { a.q_hi = ws.c_mlp_hi; a.q_ld = D; }
 #ifdef KEEP_DIAGNOSTICS
         if (!(h->dbg_skip_ln == 2 && h->dbg_calls > 3))      // dbg_skip_ln = 2: skip the attention launches instead (bounds what a faster attention could gain)
 #endif
@@ -507,7 +523,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         const int tag = cls_only ? T_VIT_TAIL : sp ? T_VIT_PROJ_X : T_VIT_PROJ;
         Scope sc(h, tag, s);
         GemmParams p = gemm_params(h, att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
-        p.ls = b.ls1; p.resid = resid;
+        p.ls = b.ls1; p.resid = resid; p.impl_hint = h->proj_impl;
         if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
         did = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
         if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
@@ -1175,6 +1191,8 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
+    else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
+    else if (n == "proj_impl") { if (v != 0 && v != 2128) return h->fail(KEEP_EINVAL, "proj_impl must be 0 or 2128"); h->proj_impl = v; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
     else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
     else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
@@ -1229,6 +1247,8 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "lane_skew") return h->lane_skew;
     if (n == "lane0_permille") return h->lane0_permille;
     if (n == "cls_tail") return h->cls_tail;
+    if (n == "proj_impl") return h->proj_impl;
+    if (n == "cls_qkv") return h->cls_qkv;
     return -1;
 }
 

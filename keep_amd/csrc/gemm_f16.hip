@@ -24,6 +24,8 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
     p.dbg = nullptr;
 #endif
     int impl = t.gemm_impl;
+    if (p.out_ld > 0 && (epi != EPI_F16 || p.out_kt > 0 || p.N % 256)) return -1;      // a strided row-major output is an EPI_F16 feature of the 256x256 kernel
+    if (p.out_ld > 0) return launch_gemm_f16_v2(p, epi, 256, s) == 0 ? 0 : -1;
     if (epi == EPI_TOP2) return launch_gemm_f16_v2(p, epi, 256, s) == 0 ? 0 : -1;      // fused prompt screening: 256x256 kernel only
     if (p.comp) {                                    // compensated product: always the 256x256 kernel (callers route small M through nseg = 3)
         return launch_gemm_f16_v2(p, epi, 256, s) == 0 ? 0 : -1;

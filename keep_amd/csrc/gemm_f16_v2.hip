@@ -618,9 +618,10 @@ void gemm_f16_v2_kernel(GemmParams p) {
     // fp16 outputs go to the blk layout (the consumer is a GEMM) or row-major (attention): ONE address form, offset(m) = (m / 256) * out_sa +
     // (m % 256) * out_sb + out_g, with the three constants picked here -- a "which layout" test per store was two scalar branches in front of each
     // of a tile's 16 stores
-    const int64_t out_sa = p.out_kt > 0 ? (int64_t)p.out_kt * 8192 : (int64_t)256 * p.N;
-    const int out_sb = p.out_kt > 0 ? 32 : p.N;
-    const int out_g = p.out_kt > 0 ? ((ncol >> 5) * 8192 + (ncol & 31)) : ncol;
+    const int out_ld = p.out_ld > 0 ? p.out_ld : p.N;
+    const int64_t out_sa = p.out_kt > 0 ? (int64_t)p.out_kt * 8192 : (int64_t)256 * out_ld;
+    const int out_sb = p.out_kt > 0 ? 32 : out_ld;
+    const int out_g = p.out_kt > 0 ? ((ncol >> 5) * 8192 + (ncol & 31)) : ncol + p.out_col0;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int mbase = m0 + wm * (TM * 32) + j * 32;
@@ -777,6 +778,8 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
         return 1;
     }
     if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, 0>(p, s);
+    if (p.impl_hint == 2128 && epi == EPI_RESID_LS && p.nseg == 1 && p.N % 128 == 0 && (p.N / 128) * ((p.M + V2_BM - 1) / V2_BM) > 2 * keep_num_cus())
+        return launch_v2_one<128, 2, 2, 3, EPI_RESID_LS, 0>(p, s);
     if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
         (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > keep_num_cus()) {
         // (a device that does not grant all 160 KiB of LDS to one workgroup falls through to the one-tile-per-workgroup launch)

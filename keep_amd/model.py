@@ -42,9 +42,15 @@ CONFIDENCE = 0.99
 PROBE_RMS_MARGIN = 1.02
 # Milliseconds a knob adds to a 256-tile encode step on an MI355X (two lanes; tools/precision_budget.py measures them, profiles/r05_precision_budget.md):
 # what the greedy of budget="measured" divides a knob's variance share by.  Only the RATIOS matter.
-KNOB_COST_MS = {"attn_split": 1.00, "mlp_comp": 0.52, "mlp_comp_w": 0.30}
-# Share of a block's MLP rounding variance that survives a treatment (same tool): both correction terms remove ~97 %, the W_lo term alone the W half
-MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_COMP_W: 0.52, _lib.MLP_COMP: 0.03, _lib.MLP_SPLIT: 0.0}
+KNOB_COST_MS = {"attn_split": 0.96, "attn_split_compqkv": 0.59, "attn_compqkv": 0.22, "mlp_comp": 0.53, "mlp_comp_w": 0.30}
+# Share of a site's rounding variance that survives a treatment when it is not measured on the loaded weights (same tool, bench weights): both
+# MX-fp4 correction terms remove ~96 % of an MLP's share, the W_lo term alone 40-55 %; a compensated qkv inside a split attention side leaves 1-2 %
+MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}
+ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_SPLIT_COMPQKV: 0.015, _lib.ATTN_SPLIT: 0.0}
+# The treatments the greedy of budget="measured" may use.  Measured on the bench weights (profiles/r05_precision_budget.md): the W_lo-only MLP form
+# removes ~45 % of a block's MLP share for 57 % of the cost of both terms, and a compensated qkv alone ~35 % of an attention side's share at 1 ms per
+# percent of variance against 0.45 for MLP blocks -- neither ever wins a greedy step, so they are off by default (``knobs=`` switches them on).
+DEFAULT_KNOBS = {"attn": (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_COMP,)}
 
 Plan = List[Tuple[int, int]]
 
@@ -159,6 +165,9 @@ class KEEPModel:
         # (against the engine's own split-product arithmetic) predicts a worst error inside the tolerance over CALIBRATION_POPULATION cosines.  KEEP_CALIBRATE=0 / auto_calibrate=False: keep the
         # built-in default (1, 8), which was chosen on ONE synthetic weight family.
         self.auto_calibrate = os.environ.get("KEEP_CALIBRATE", "1") != "0"
+        # "measured": one split-product encode of a 64-tile probe per block and half ranks the knobs for THESE weights, then a greedy plan is verified
+        # (about 2 s at load for ViT-L); "ladder": the prefix family COMP_LADDER only (under 1 s, up to 12 % slower plans -- profiles/r05_precision_budget.md)
+        self.calibration_budget = os.environ.get("KEEP_CALIBRATION_BUDGET", "measured")
         self.calibration: Optional[dict] = None
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
@@ -376,7 +385,7 @@ class KEEPModel:
     @torch.no_grad()
     def calibrate(self, n_tiles: int = 256, population: Optional[float] = None, tiles: Optional[torch.Tensor] = None,
                   text_features: Optional[torch.Tensor] = None, seed: int = 20250929, tolerance: float = TOLERANCE,
-                  confidence: float = CONFIDENCE, budget: str = "ladder") -> Optional[dict]:
+                  confidence: float = CONFIDENCE, budget: Optional[str] = None, knobs: Optional[Mapping] = None) -> Optional[dict]:
         """Pick the 'comp' plan for THESE weights and for the population the model will be used on.
 
         A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded once with split
@@ -403,6 +412,7 @@ class KEEPModel:
                 return self.calibration
         if not h.value or lib.keep_vit_depth(h) == 0 or self._options["precision"] != _lib.PREC_COMP:
             return None
+        budget = budget or self.calibration_budget
         if budget not in ("ladder", "measured"):
             raise ValueError("budget must be 'ladder' or 'measured'")
         dev, depth = self._device, int(lib.keep_vit_depth(h))
@@ -461,8 +471,13 @@ class KEEPModel:
                     if consider(prefix_plan(depth, full, mlp)):
                         break
             else:
-                shares = self._measure_shares(tiles, bank, ref, depth)
-                for plan in self._greedy_plans(shares, depth, rms_target):
+                n_sh = min(tiles.shape[0], 64)             # the shares only rank the knobs: a quarter of the probe is enough (and 4 x faster)
+                shares = self._measure_shares(tiles[:n_sh], bank, ref[:n_sh], depth)
+                walk = self._greedy_walk(shares, depth, knobs or DEFAULT_KNOBS)
+                # the sum of measured shares over-predicts the rms of a plan by 3-11 % (variances of neighbouring sites do not quite add): start the
+                # verification a little before the predicted crossing and walk up one knob at a time until a plan verifies
+                start = next((i for i, (_, v) in enumerate(walk) if v <= (1.06 * rms_target) ** 2), len(walk) - 1)
+                for plan, _ in walk[start:]:
                     if consider(plan):
                         break
             if chosen is None:
@@ -503,67 +518,63 @@ class KEEPModel:
     def _measure_shares(self, tiles, bank, ref, depth: int) -> dict:
         """Cosine-error variance each block's attention side / MLP contributes when it alone runs single fp16 passes and everything else split
         products (so the figure is that site's own rounding error, not the re-drawn rounding of everything downstream), plus what is left of a
-        block's MLP share under the two compensated forms, measured on block 0 and on a middle block."""
+        site's share under the cheaper treatments, measured on block 0 (and a middle block for the MLP forms)."""
         split = [(_lib.ATTN_SPLIT, _lib.MLP_SPLIT)] * depth
 
-        def var_of(plan):
-            self.set_plan(plan)
+        def var_of(i, mode):
+            p = list(split)
+            p[i] = mode
+            self.set_plan(p)
             d = self.similarity(self.encode_image(tiles), bank).sub_(ref)
             return float(d.pow(2).mean())
 
-        attn, mlp = [], []
-        for i in range(depth):
-            p = list(split); p[i] = (_lib.ATTN_PLAIN, _lib.MLP_SPLIT); attn.append(var_of(p))
-            p = list(split); p[i] = (_lib.ATTN_SPLIT, _lib.MLP_PLAIN); mlp.append(var_of(p))
-        floor = var_of(split)
-        res = {}
-        for mode, name in ((_lib.MLP_COMP, "mlp_comp"), (_lib.MLP_COMP_W, "mlp_comp_w")):
-            fr = []
-            for i in sorted({0, depth // 2}):
-                p = list(split); p[i] = (_lib.ATTN_SPLIT, mode)
-                if mlp[i] > floor:
-                    fr.append(max(var_of(p) - floor, 0.0) / (mlp[i] - floor))
-            res[name] = sum(fr) / len(fr) if fr else MLP_RESIDUAL[mode]
-        return {"attn": [max(v - floor, 0.0) for v in attn], "mlp": [max(v - floor, 0.0) for v in mlp], "floor": floor, "residual": res}
+        self.set_plan(split)
+        floor = float(self.similarity(self.encode_image(tiles), bank).sub_(ref).pow(2).mean())
+        attn = [max(var_of(i, (_lib.ATTN_PLAIN, _lib.MLP_SPLIT)) - floor, 0.0) for i in range(depth)]
+        mlp = [max(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_PLAIN)) - floor, 0.0) for i in range(depth)]
+        res_m, res_a = dict(MLP_RESIDUAL), dict(ATTN_RESIDUAL)
+        for mode in (_lib.MLP_COMP, _lib.MLP_COMP_W):
+            fr = [max(var_of(i, (_lib.ATTN_SPLIT, mode)) - floor, 0.0) / mlp[i] for i in sorted({0, depth // 2}) if mlp[i] > 0]
+            if fr:
+                res_m[mode] = min(sum(fr) / len(fr), 1.0)
+        for mode in (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_COMPQKV):
+            if attn[0] > 0:
+                res_a[mode] = min(max(var_of(0, (mode, _lib.MLP_SPLIT)) - floor, 0.0) / attn[0], 1.0)
+        attn, mlp, floor = [float(f"{v:.3e}") for v in attn], [float(f"{v:.3e}") for v in mlp], float(f"{floor:.3e}")
+        return {"attn": attn, "mlp": mlp, "floor": floor, "residual_mlp": {int(k): float(f"{v:.4f}") for k, v in res_m.items()},
+                "residual_attn": {int(k): float(f"{v:.4f}") for k, v in res_a.items()}, "probe_tiles": int(tiles.shape[0])}
 
-    def _greedy_plans(self, shares: dict, depth: int, rms_target: float):
-        """Plans in order of predicted cost: start from all-plain, repeatedly take the upgrade with the largest variance reduction per millisecond
-        (KNOB_COST_MS) and yield the plan every time the PREDICTED rms is inside the target -- the caller verifies each by encoding the probe; a
-        verified miss simply continues the walk.  Ends with the all-split plan."""
-        r_c, r_w = shares["residual"]["mlp_comp"], shares["residual"]["mlp_comp_w"]
-        attn_mode, mlp_mode = [_lib.ATTN_PLAIN] * depth, [_lib.MLP_PLAIN] * depth
-        left_m = {_lib.MLP_PLAIN: 1.0, _lib.MLP_COMP_W: r_w, _lib.MLP_COMP: r_c}
-        cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"]}
+    @staticmethod
+    def _greedy_walk(shares: dict, depth: int, knobs: Mapping) -> List[Tuple[Plan, float]]:
+        """[(plan, predicted cosine-error variance)] from the all-plain plan upwards: every step takes the ONE upgrade (a block's attention side or
+        MLP to one of the allowed treatments) with the largest predicted variance reduction per millisecond (KNOB_COST_MS); the last entry has
+        every site at its best allowed treatment."""
+        res_a, res_m = shares["residual_attn"], shares["residual_mlp"]
+        cost_a = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"], _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"],
+                  _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
+        cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"], _lib.MLP_SPLIT: 3.0 * KNOB_COST_MS["mlp_comp"]}
+        am, mm = [_lib.ATTN_PLAIN] * depth, [_lib.MLP_PLAIN] * depth
 
         def predicted():
-            v = shares["floor"]
-            for i in range(depth):
-                v += shares["attn"][i] * (0.0 if attn_mode[i] == _lib.ATTN_SPLIT else 1.0) + shares["mlp"][i] * left_m[mlp_mode[i]]
-            return v
+            return shares["floor"] + sum(shares["attn"][i] * res_a[am[i]] + shares["mlp"][i] * res_m[mm[i]] for i in range(depth))
 
-        last = None
-        for _ in range(3 * depth + 1):
-            if predicted() <= rms_target ** 2:
-                plan = list(zip(attn_mode, mlp_mode))
-                if plan != last:
-                    last = plan
-                    yield plan
-            best, best_gain = None, 0.0
+        walk = [(list(zip(am, mm)), predicted())]
+        while True:
+            best, gain = None, 0.0
             for i in range(depth):
-                if attn_mode[i] == _lib.ATTN_PLAIN and shares["attn"][i] / KNOB_COST_MS["attn_split"] > best_gain:
-                    best, best_gain = ("a", i, _lib.ATTN_SPLIT), shares["attn"][i] / KNOB_COST_MS["attn_split"]
-                for m in (_lib.MLP_COMP_W, _lib.MLP_COMP):
-                    dc = cost_m[m] - cost_m[mlp_mode[i]]
-                    dv = shares["mlp"][i] * (left_m[mlp_mode[i]] - left_m[m])
-                    if dc > 0 and dv / dc > best_gain:
-                        best, best_gain = ("m", i, m), dv / dc
+                for a in knobs.get("attn", ()):
+                    dc, dv = cost_a[a] - cost_a[am[i]], shares["attn"][i] * (res_a[am[i]] - res_a[a])
+                    if dc > 0 and dv > 0 and dv / dc > gain:
+                        best, gain = (am, i, a), dv / dc
+                for m in knobs.get("mlp", ()):
+                    dc, dv = cost_m[m] - cost_m[mm[i]], shares["mlp"][i] * (res_m[mm[i]] - res_m[m])
+                    if dc > 0 and dv > 0 and dv / dc > gain:
+                        best, gain = (mm, i, m), dv / dc
             if best is None:
                 break
-            if best[0] == "a":
-                attn_mode[best[1]] = best[2]
-            else:
-                mlp_mode[best[1]] = best[2]
-        yield [(_lib.ATTN_SPLIT, _lib.MLP_SPLIT)] * depth
+            best[0][best[1]] = best[2]
+            walk.append((list(zip(am, mm)), predicted()))
+        return walk
 
     def get_option(self, name: str) -> float:
         self._ready_device()

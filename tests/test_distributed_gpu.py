@@ -90,7 +90,7 @@ def _rccl_worker(rank, world, port, n_tiles, q):
         m = KEEPModel(shape, towers=("image",))
         m.load_state_dict(synth_state_dict(shape, seed=3, text=False), strict=True)
         m.to(dev).eval()
-        setting = assert_same_setting([m.get_option("comp_full_blocks"), m.get_option("comp_mlp_blocks")], device=dev)
+        setting = assert_same_setting([float(v) for am in m.get_plan() for v in am], device=dev)
         load = lambda a, b: synth_tiles_device(a, b, dev, torch.bfloat16, seed=77, unit=64)
         got = encode_tiles_sharded(m.encode_image, n_tiles, load, batch=32)           # ragged shards, pipelined all-gathers
         ref = torch.cat([m.encode_image(load(a, min(a + 32, n_tiles))) for a in range(0, n_tiles, 32)])

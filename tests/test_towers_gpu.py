@@ -407,6 +407,31 @@ def test_cls_only_tail_is_exact(small, no_splitk):
         assert (fast - full).abs().max() < 2e-6
 
 
+def test_last_block_query_for_the_cls_rows_only(small):
+    """Lanes of >= 32 tiles: the last block's qkv GEMM computes K | V for every token and Q for the CLS rows alone (a [B, D] x W_q^T product on the
+    small-M kernel, engine option cls_qkv, default on) -- every other token's query is never read.  Same features as with all 3 D columns computed,
+    to the fp16 rounding of the CLS query (the two kernels sum K in different orders); both inside the mode's tolerance of the oracle."""
+    x = synth_tiles(70, seed=17)                                   # two lanes of 35 tiles
+    with torch.no_grad():
+        ref = O.encode_image(small, x)
+    for precision in ("fp16", "comp"):
+        m = make_model(small, precision)
+        m.profile_enable("vit.tail")
+        m.profile_reset()
+        fast = m.encode_image(x.cuda())
+        torch.cuda.synchronize()
+        n_tail = m.profile_read("vit.tail")[1]
+        m.set_option("cls_qkv", 0)
+        m.profile_reset()
+        full = m.encode_image(x.cuda())
+        torch.cuda.synchronize()
+        assert n_tail > m.profile_read("vit.tail")[1]             # the CLS-query gather + GEMM did run (timed under the tail tag)
+        m.profile_disable()
+        d = (fast - full).norm(dim=1).max().item()
+        print(f"[cls_qkv {precision}] |fast - full| {d:.3e}; vs oracle fast {(fast.cpu() - ref).norm(dim=1).max():.3e} full {(full.cpu() - ref).norm(dim=1).max():.3e}")
+        assert d < 2e-4 and (fast.cpu() - ref).norm(dim=1).max() < 1.2 * max((full.cpu() - ref).norm(dim=1).max().item(), 1e-5)
+
+
 # ------------------------------------------------------------------ full depth vs golden (HF outputs)
 @pytest.mark.parametrize("precision", MODES)
 def test_full_depth_image_tower_vs_golden(golden_dir, text_bank, precision):
@@ -698,7 +723,7 @@ def test_weight_families_calibrated_default_mode_within_tolerance(golden_dir, fa
     txt = m.encode_text({k: v.cuda() for k, v in toks.items()})
     sim, lab = m.classify(x.cuda(), txt)
     d = (sim.cpu() - ref).abs()
-    print(f"[family {family}] calibrated to {cal['precision']} {cal['comp_full_blocks']}/{cal['comp_mlp_blocks']} after {len(cal['tried'])} rung(s) "
+    print(f"[family {family}] calibrated to {cal['precision']} {cal['plan']} after {len(cal['tried'])} candidate(s) "
           f"(probe errors {[t['max_abs_dcos'] for t in cal['tried']]}); max|dcos| vs oracle {d.max():.3e} rms {d.pow(2).mean().sqrt():.3e}; "
           f"{m.last_rechecked} tiles encoded twice; smallest oracle margin {float(margin.min()):.2e}")
     assert d.max() < COS_TOL
@@ -714,28 +739,42 @@ def test_weight_families_calibrated_default_mode_within_tolerance(golden_dir, fa
     print(f"[family {family}] built-in 1/8 without calibration: max|dcos| {d2.max():.3e}")
 
 
-def test_calibrate_walks_the_ladder_and_reports(small):
+@pytest.mark.parametrize("budget", ["ladder", "measured"])
+def test_calibrate_walks_its_candidates_and_reports(small, budget):
+    from keep_amd.model import plan_string
     m = make_model(small, "comp")
-    assert m.calibration["precision"] == "comp" and m.calibration["comp_full_blocks"] <= 2       # depth-2 model: rungs clamp to its depth
-    assert m.get_option("comp_full_blocks") == m.calibration["comp_full_blocks"] and m.get_option("comp_mlp_blocks") == m.calibration["comp_mlp_blocks"]
-    # an unreachable target walks every rung and ends in the split-product mode
-    cal = m.calibrate(n_tiles=64, tolerance=1e-9)
-    assert cal["precision"] == "strict" and len(cal["tried"]) >= 2 and m.get_option("precision") == 1
+    assert m.calibration["precision"] == "comp" and m.calibration["budget"] == m.calibration_budget == "measured"      # what load_state_dict ran
+    assert plan_string(m.get_plan()) == m.calibration["plan"]
+
+    def cost(c):                                               # a plan's price in knobs: an attention side counts double
+        if c["precision"] != "comp":
+            return 99
+        a, mm = (part.split(":")[1] for part in c["plan"].split())
+        return sum(2 * (ch != "0") for ch in a) + sum(ch != "0" for ch in mm)
+
+    # an unreachable target tries its candidates and ends in the split-product mode
+    cal = m.calibrate(n_tiles=64, tolerance=1e-9, budget=budget)
+    assert cal["precision"] == "strict" and cal["budget"] == budget and len(cal["tried"]) >= (2 if budget == "ladder" else 1) and m.get_option("precision") == 1
     errs = [t["max_abs_dcos"] for t in cal["tried"]]
     assert errs[-1] <= errs[0] * 1.2                       # more compensated blocks: not worse
     x = synth_tiles(4, seed=2).cuda()
     with torch.no_grad():
         ref = O.encode_image(small, x.cpu())
     assert (m.encode_image(x).cpu() - ref).abs().max() < 5e-6
-    # a generous target keeps the first rung; explicit probe tiles and prompts are accepted
+    # a generous target keeps the cheapest candidate; explicit probe tiles and prompts are accepted
     m.set_precision("comp")
-    cal = m.calibrate(tiles=synth_tiles(40, seed=9).to(torch.bfloat16), text_features=torch.nn.functional.normalize(torch.randn(7, 768), dim=-1), tolerance=1e-2)
-    assert cal["precision"] == "comp" and len(cal["tried"]) == 1 and "40 tiles x 7 prompts" in cal["probe"]
+    cal = m.calibrate(tiles=synth_tiles(40, seed=9).to(torch.bfloat16), text_features=torch.nn.functional.normalize(torch.randn(7, 768), dim=-1), tolerance=1e-2,
+                      budget=budget)
+    assert cal["precision"] == "comp" and len(cal["tried"]) == 1 and "40 tiles x 7 prompts" in cal["probe"] and cost(cal) == 0
+    if budget == "measured":
+        sh = cal["variance_shares"]
+        assert len(sh["attn"]) == len(sh["mlp"]) == 2 and sh["floor"] < min(sh["mlp"]) and sh["residual_mlp"][2] < 0.3
     # the rule is population-aware: a larger population (more tiles x distinct prompts to compare) asks for a smaller rms, never a larger one
-    small_pop, large_pop = m.calibrate(population=1e4), m.calibrate(population=1e9)
+    small_pop, large_pop = m.calibrate(population=1e4, budget=budget), m.calibrate(population=1e9, budget=budget)
     assert small_pop["target_rms_dcos"] > large_pop["target_rms_dcos"] and small_pop["max_sigmas_quantile"] < large_pop["max_sigmas_quantile"]
+    assert cost(small_pop) <= cost(large_pop)
     # ... and confidence-aware: the quantile sits above the location of the maximum, the more so the higher the confidence
-    lo, hi = m.calibrate(confidence=0.5), m.calibrate(confidence=0.999)
+    lo, hi = m.calibrate(confidence=0.5, budget=budget), m.calibrate(confidence=0.999, budget=budget)
     assert lo["expected_max_sigmas"] < lo["max_sigmas_quantile"] < hi["max_sigmas_quantile"] and lo["target_rms_dcos"] > hi["target_rms_dcos"]
     for c in (lo, hi):
         if c["precision"] == "comp":
@@ -743,11 +782,9 @@ def test_calibrate_walks_the_ladder_and_reports(small):
             assert c["label_margin"] == pytest.approx(2 ** 0.5 * c["predicted_max_abs_dcos"], rel=1e-2)
     if hi["precision"] == "comp":
         assert m.get_option("label_margin") == pytest.approx(hi["label_margin"], rel=1e-3)         # the last calibration set the engine's second-look threshold
-    rung = lambda c: (c["comp_full_blocks"] if c["precision"] == "comp" else 99, c["comp_mlp_blocks"] if c["precision"] == "comp" else 99)
-    assert rung(small_pop) <= rung(large_pop)
     # strict_blocks set by the caller survives a calibration (it used to be reset to 0)
     m.set_precision("comp", strict_blocks=1)
-    m.calibrate()
+    m.calibrate(budget=budget)
     assert m.get_option("strict_blocks") == 1 and m.calibration["strict_blocks"] == 1
     fp = make_model(small, "fp16")
     assert fp.calibration is None and fp.calibrate() is None            # only the compensated mode has something to choose
