@@ -180,7 +180,8 @@ int keep_encode_image(keep_handle* h, const void* pixels, int pix_dtype, int64_t
 /* Replaces: KEEPModel.encode_text  (quick_start/keep_inference.py:60-62)
  *   input_ids / token_type_ids / attention_mask: int64 [P,T] (the tokenizer's return_tensors='pt'
  *   layout, keep_inference.py:99); token_type_ids and attention_mask may be NULL (zeros / ones, as
- *   HF BertModel defaults).  out: fp32 [P,768] L2-normalised.  T <= 512 (256 in strict mode). */
+ *   HF BertModel defaults).  out: fp32 [P,768] L2-normalised.  T <= 512 (BertModel's max_position_embeddings) in every precision mode: above 256 keys
+ *   the split-product attention of KEEP_PREC_COMP / KEEP_PREC_STRICT runs over two key windows and merges them (the exact softmax over all keys). */
 int keep_encode_text(keep_handle* h, const int64_t* input_ids, const int64_t* token_type_ids,
                      const int64_t* attention_mask, int64_t P, int64_t T, float* out, void* stream);
 

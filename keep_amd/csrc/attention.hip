@@ -130,12 +130,15 @@ void attention_kernel(AttnParams p) {
 
     long long t_start = 0, t_staged = 0;
     if (p.dbg) t_start = __builtin_readcyclecounter();
-    stage_kv<NT, ATT_THREADS>(base_hi, ntok, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
-    if (SPLIT) stage_kv<NT, ATT_THREADS>(base_lo, ntok, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
+    // key window of this launch (all keys unless launch_attention split a long sequence in two)
+    const int key0 = SPLIT ? p.key0 : 0;
+    const int kcount = (SPLIT && p.kcount > 0) ? p.kcount : ntok;
+    stage_kv<NT, ATT_THREADS>(base_hi + (int64_t)key0 * D3, kcount, D3, D + h * HD, 2 * D + h * HD, sK, sVt, tid, wave);
+    if (SPLIT) stage_kv<NT, ATT_THREADS>(base_lo + (int64_t)key0 * D3, kcount, D3, D + h * HD, 2 * D + h * HD, sKl, sVtl, tid, wave);
     for (int k = tid; k < NKP; k += ATT_THREADS) {
         float bias = 0.f;
-        if (k >= ntok) bias = -INFINITY;
-        else if (p.mask && p.mask[tok0 + k] == 0) bias = -1e30f;     // HF adds finfo.min to masked keys
+        if (k >= kcount) bias = -INFINITY;
+        else if (p.mask && p.mask[tok0 + key0 + k] == 0) bias = -1e30f;     // HF adds finfo.min to masked keys
         sBias[k] = bias;                                             // (scores live in the log2 domain below; -1e30 / -inf are scale-free)
     }
     // The K tiles arrive by LDS-DMA: nothing but this wave's own vmcnt orders them before the barrier.
@@ -253,7 +256,7 @@ void attention_kernel(AttnParams p) {
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
+        float inv = 1.0f / sum;
 
         // ---- O^T = V^T P^T
         f32x4 o[4];
@@ -301,6 +304,31 @@ void attention_kernel(AttnParams p) {
         // loads themselves are outstanding, and they were issued a whole tile ago.
         asm volatile("" : "+v"(qn[0]), "+v"(qn[1]));
         if (SPLIT) asm volatile("" : "+v"(qln[0]), "+v"(qln[1]));
+        if constexpr (SPLIT) {
+            // two key windows (256 < ntok <= 512): the first launch parks (unnormalised O, maximum, sum) per query, the second merges:
+            // m = max(m1, m2); O = O1 2^(m1 - m) + O2 2^(m2 - m); l likewise -- exactly the softmax over all keys (scores are in the log2 domain)
+            const int64_t prow = ((int64_t)(b * p.heads + h) * ntok + (q < ntok ? q : ntok - 1)) * ATT_PART_FLOATS;
+            if (p.part_out) {
+                if (q < nq) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(p.part_out + prow + dt * 16 + g * 4) = o[dt];
+                    if (g == 0) { p.part_out[prow + 64] = mx; p.part_out[prow + 65] = sum; }
+                }
+                continue;
+            }
+            if (p.part_in) {
+                const float m1 = p.part_in[prow + 64], l1 = p.part_in[prow + 65];
+                const float m = fmaxf(m1, mx);
+                const float w1 = __builtin_amdgcn_exp2f(m1 - m), w2 = __builtin_amdgcn_exp2f(mx - m);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f32x4 o1 = *reinterpret_cast<const f32x4*>(p.part_in + prow + dt * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[dt][r] = o1[r] * w1 + o[dt][r] * w2;
+                }
+                inv = 1.0f / (l1 * w1 + sum * w2);
+            }
+        }
         if (q < nq) {
             const int mrow = (int)(tok0 + q);
 #pragma unroll
@@ -524,6 +552,7 @@ int launch_one(const AttnParams& p, hipStream_t s) {
 int launch_attention(const AttnParams& p_in, hipStream_t s) {
     using namespace keepk;
     AttnParams p = p_in;
+    p.key0 = 0; p.kcount = 0; p.part_out = nullptr; p.part_in = nullptr;      // internal fields: set below for the two-window launches only
     const int g_attn_waves = p.tune ? p.tune->attn_waves : 8;     // wavefronts per workgroup for the unsplit 13/16-tile kernels (4 or 8)
 #ifdef KEEP_DIAGNOSTICS
     p.dbg = p.tune ? p.tune->dbg : nullptr;
@@ -540,6 +569,14 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
         if (nt <= 8) return launch_one<8, true, 4>(p, s);
         if (nt <= 13) return launch_one<13, true, 4>(p, s);
         if (nt <= 16) return launch_one<16, true, 4>(p, s);
+        if (nt <= 32 && p.part_ws && p.part_bytes >= (size_t)p.batch * p.heads * p.ntok * ATT_PART_FLOATS * sizeof(float)) {
+            // K / V hi + lo of 512 keys are 256 KiB: two key windows of <= 256, merged in the second launch (same stream: ordered)
+            AttnParams a = p, c = p;
+            a.key0 = 0; a.kcount = 256; a.part_out = p.part_ws; a.part_in = nullptr;
+            c.key0 = 256; c.kcount = p.ntok - 256; c.part_out = nullptr; c.part_in = p.part_ws;
+            const int rc = launch_one<16, true, 4>(a, s);
+            return rc ? rc : launch_one<16, true, 4>(c, s);
+        }
         return -1;
     }
     if (nt <= 4) return launch_one<4, false, 4>(p, s);

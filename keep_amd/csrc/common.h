@@ -152,11 +152,18 @@ struct AttnParams {
     const f16* q_hi; int q_ld;            // q_rows == 1 only, nullable: the ONE query row of image b at q_hi + b * q_ld (head-major, like the q part of a qkv row) instead of
                                           // qkv_hi -- the last block computes Q for its CLS rows only
     int split;                            // 0/1
+    // split mode with 256 < ntok <= 512: the K / V planes (hi + lo) of more than 256 keys do not fit the LDS, so the keys are processed in two
+    // windows of <= 256 (two launches) and merged like an online softmax.  part_ws: caller's scratch, batch * heads * ntok * ATT_PART_FLOATS floats
+    // (unnormalised output row + running maximum + sum per query); launch_attention fills key0 / kcount / part_out / part_in itself.
+    float* part_ws; size_t part_bytes;
+    int key0, kcount;                     // internal: key window [key0, key0 + kcount) of this launch (kcount 0 = all keys)
+    float* part_out; const float* part_in;   // internal: first window writes its partial state, second window merges it and stores the result
     float scale;                          // 1/sqrt(64)
     long long* dbg;                       // diagnostics: per-workgroup [start, staged, end] shader clocks (tools/attn_timeline.py)
     const KeepTune* tune;
 };
 int launch_attention(const AttnParams& p, hipStream_t s);   // returns 0 or -1 (unsupported ntok)
+constexpr int ATT_PART_FLOATS = 66;       // 64 output features + maximum + sum
 
 // LayerNorm over rows of D in {768,1024}; fp32 in, fp16 (hi[,lo]) and/or fp32 out.
 struct LnParams {

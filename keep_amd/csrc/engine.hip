@@ -192,11 +192,9 @@ struct keep_handle {
         if (m == KEEP_MLP_COMP || m == KEEP_MLP_COMP_W) return (lane_tiles >= comp_min_tiles && vit_has_q) ? m : KEEP_MLP_SPLIT;
         return m;
     }
-    // the text tower is 1 % of a slide's work: in the compensated mode it simply runs split products throughout
-    // (the split attention kernel covers T <= 256, the reference's max_length; in the compensated mode longer sequences fall back to
-    // single fp16 passes instead of failing -- strict mode and strict_blocks reject them)
-    bool txt_split(int l, int T) const { return precision == KEEP_PREC_STRICT || l < strict_blocks || (precision == KEEP_PREC_COMP && T <= 256); }
-    bool txt_must_split() const { return precision == KEEP_PREC_STRICT || strict_blocks > 0; }
+    // the text tower is 1 % of a slide's work: in the compensated mode it simply runs split products throughout, at every length BertModel accepts
+    // (T <= 512 = max_position_embeddings; above 256 keys the split attention runs as two key windows of <= 256, merged like an online softmax)
+    bool txt_split(int l, int T) const { (void)T; return precision == KEEP_PREC_STRICT || l < strict_blocks || precision == KEEP_PREC_COMP; }
     bool any_split() const { return precision != KEEP_PREC_FP16 || strict_blocks > 0; }
     bool vit_has_q = false;      // every fc1 / fc2 weight has its fp4 side planes (dims % 128 == 0)
     bool any_comp() const {
@@ -282,7 +280,7 @@ struct VitWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo
                unsigned char *xn_q, *xn_sc, *mlp_q, *mlp_sc;     // MX-fp4 side planes of the LayerNorm-2 output and of the MLP hidden (compensated mode)
                // compact CLS-row buffers for the last block
                float* c_resid; f16 *c_att_hi, *c_att_lo, *c_xn_hi, *c_xn_lo, *c_mlp_hi, *c_mlp_lo; };
-struct TxtWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; };
+struct TxtWs { float* splitk; float* resid; f16 *xn_hi, *xn_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *mlp_hi, *mlp_lo; float* attn_part; size_t attn_part_bytes; };
 
 size_t vit_ws_bytes(const keep_handle* h, int64_t Bc, bool split) {
     const size_t M = (size_t)Bc * 197, Mp = (size_t)Bc * 196, D = h->vit_D, F = h->vit_F, k = split ? 2 : 1;
@@ -316,7 +314,9 @@ VitWs carve_vit(const keep_handle* h, char* arena, int64_t Bc, bool split) {
 }
 size_t txt_ws_bytes(const keep_handle* h, int64_t Pc, int64_t T, bool split) {
     const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F, k = split ? 2 : 1;
-    return align_up(SKINNY_WS_BYTES) + align_up(M * H * 4) + k * (align_up(blk_elems(M, H) * 2) * 2 + align_up(M * 3 * H * 2) + align_up(blk_elems(M, F) * 2)) + 4096;
+    // split attention over more than 256 keys parks a partial state per (prompt, head, query) between its two key windows
+    const size_t part = (split && T > 256) ? align_up((size_t)Pc * h->bert_heads * T * ATT_PART_FLOATS * sizeof(float)) : 0;
+    return align_up(SKINNY_WS_BYTES) + align_up(M * H * 4) + k * (align_up(blk_elems(M, H) * 2) * 2 + align_up(M * 3 * H * 2) + align_up(blk_elems(M, F) * 2)) + part + 4096;
 }
 TxtWs carve_txt(const keep_handle* h, char* arena, int64_t Pc, int64_t T, bool split) {
     const size_t M = (size_t)Pc * T, H = h->bert_H, F = h->bert_F;
@@ -327,6 +327,10 @@ TxtWs carve_txt(const keep_handle* h, char* arena, int64_t Pc, int64_t T, bool s
     w.qkv_hi = c.take<f16>(M * 3 * H);       w.qkv_lo = split ? c.take<f16>(M * 3 * H) : nullptr;
     w.att_hi = c.take<f16>(blk_elems(M, H)); w.att_lo = split ? c.take<f16>(blk_elems(M, H)) : nullptr;
     w.mlp_hi = c.take<f16>(blk_elems(M, F)); w.mlp_lo = split ? c.take<f16>(blk_elems(M, F)) : nullptr;
+    if (split && T > 256) {
+        w.attn_part_bytes = (size_t)Pc * h->bert_heads * T * ATT_PART_FLOATS * sizeof(float);
+        w.attn_part = c.take<float>(w.attn_part_bytes / sizeof(float));
+    }
     return w;
 }
 
@@ -624,8 +628,8 @@ int txt_chunk(keep_handle* h, const int64_t* ids, const int64_t* types, const in
             a.tune = &h->tune;
             a.qkv_hi = ws.qkv_hi; a.qkv_lo = ws.qkv_lo; a.out_hi = ws.att_hi; a.out_lo = sp ? ws.att_lo : nullptr;
             a.mask = mask; a.batch = Pc; a.ntok = T; a.heads = h->bert_heads; a.split = sp; a.scale = 0.125f; a.out_kt = H / 32;
-            if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %d unsupported%s", T,
-                                                       sp ? " in strict mode (max 256)" : " (max 512)");
+            a.part_ws = ws.attn_part; a.part_bytes = ws.attn_part_bytes;
+            if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %d unsupported (max 512)", T);
         }
         LnParams ln{};
         ln.tune = &h->tune;
@@ -1310,7 +1314,7 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
     if (!h->finalized || !h->bert_layers) return h->fail(KEEP_ESTATE, "text tower not loaded / finalised");
     if (!ids || !out || P < 0 || T < 1) return h->fail(KEEP_EINVAL, "null pointer or bad shape");
     if (T > h->bert_maxpos) return h->fail(KEEP_EINVAL, "sequence length %lld exceeds max_position_embeddings %d", (long long)T, h->bert_maxpos);
-    if (T > 512 || (h->txt_must_split() && T > 256)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);
+    if (T > 512) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported (the attention kernels cover 512 tokens, BertModel's max_position_embeddings)", (long long)T);
     if (P == 0) return KEEP_OK;
     KEEP_ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
@@ -1745,6 +1749,11 @@ int keep_op_attention(keep_handle* h, const float* qkv, const int64_t* mask, int
     launch_split_f16(qkv, q_hi, q_lo, M * 3 * D, s);
     AttnParams a{};
     a.tune = &h->tune;
+    if (split && T > 256) {
+        a.part_bytes = (size_t)B * heads * T * ATT_PART_FLOATS * sizeof(float);
+        a.part_ws = t.get<float>(a.part_bytes / sizeof(float));
+        if (!a.part_ws) return h->fail(KEEP_ENOMEM, "temp alloc");
+    }
     a.qkv_hi = q_hi; a.qkv_lo = q_lo; a.out_hi = o_hi; a.out_lo = split ? o_lo : nullptr; a.mask = mask;
     a.batch = (int)B; a.ntok = (int)T; a.heads = heads; a.split = split; a.scale = 0.125f; a.out_kt = (int)(D / 32);
     if (launch_attention(a, s)) return h->fail(KEEP_EUNSUPPORTED, "sequence length %lld unsupported", (long long)T);

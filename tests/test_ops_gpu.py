@@ -342,6 +342,29 @@ def test_attention_512_tokens(ops):
     qkv = rand(B * T, 3 * heads * 64, seed=23)
     out = ops.attention(qkv, B, T, heads, None, False).cpu().double()
     assert (out - attn_ref(qkv, B, T, heads, None, True)).abs().max() < 4e-3
+
+
+@pytest.mark.parametrize("T", [512, 257, 400])
+def test_split_attention_over_two_key_windows(ops, T):
+    """Split products above 256 keys: K / V hi + lo of one window fill the LDS, so the keys are processed as [0, 256) and [256, T) in two launches,
+    the second merging the first one's (unnormalised output, running maximum, sum) per query -- the exact softmax over all keys.  Unmasked, with
+    key-padding masks ending in either window, with a hole, and with a second window that is padding only."""
+    B, heads = 4, 3
+    qkv = rand(B * T, 3 * heads * 64, seed=26, std=1.5)
+    out = ops.attention(qkv, B, T, heads, None, True).cpu().double()
+    assert (out - attn_ref(qkv, B, T, heads, None, False)).abs().max() < 3e-5
+    mask = torch.ones(B, T, dtype=torch.int64)
+    mask[0, 100:] = 0                       # everything in the second window (and most of the first) is padding
+    mask[1, 256:] = 0                       # exactly the second window is padding
+    mask[2, T - 1:] = 0
+    mask[3, 7] = 0; mask[3, 300 if T > 300 else 256] = 0      # holes in both windows
+    out = ops.attention(qkv, B, T, heads, mask, True).cpu().double()
+    assert (out - attn_ref(qkv, B, T, heads, mask, False)).abs().max() < 3e-5
+    # no valid key at all: HF adds finfo.min everywhere -> a uniform average over ALL T keys, across both windows
+    none = torch.zeros(1, T, dtype=torch.int64)
+    q1 = qkv[:T, :192].contiguous()
+    out = ops.attention(q1, 1, T, 1, none, True).cpu().double()
+    assert (out - q1[:, 128:192].double().mean(0, keepdim=True)).abs().max() < 1e-5
     with pytest.raises(ValueError):
         ops.attention(rand(600, 192), 1, 600, 1)
 
