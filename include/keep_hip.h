@@ -154,6 +154,15 @@ double keep_get_option(keep_handle* h, const char* name);
  * final cosine is a property of the checkpoint, measured by KEEPModel.calibrate / tools/precision_budget.py.  Sub-batches below "comp_min_tiles"
  * run split products wherever a compensated one is planned.  KEEP_PREC_STRICT / "strict_blocks" override the plan; KEEP_PREC_FP16 ignores it. */
 int keep_set_block_precision(keep_handle* h, int block, int attn_mode, int mlp_mode);
+/* Mean-input compensation of the weight-rounding error (replaces nothing in the reference, which multiplies in fp32: quick_start/keep_inference.py:54-58).
+ * A single-pass fp16 GEMM drops the term W_lo A_hi^T.  Part of it is the same for every row: W_lo a_mean, a_mean = the mean input row of that GEMM (GELU
+ * outputs are positive, LayerNorm outputs carry their bias, attention outputs are averages) -- 10-50 % of that GEMM's weight-rounding variance on the
+ * synthetic checkpoints, and the one part of the rounding error that does not average out over a slide's tiles.  It is a constant vector per GEMM: this call
+ * encodes the B calibration tiles (>= 8; KEEP_PIX_* layouts as keep_encode_image) in split products, averages the input rows of the four GEMMs of every ViT
+ * block and stores bias + W_lo a_mean; every PLAIN launch (KEEP_ATTN_PLAIN / KEEP_MLP_PLAIN, KEEP_PREC_FP16) then uses that bias -- zero cost per call.  Split and
+ * compensated launches compute the term itself and keep the checkpoint's bias.  B = 0 forgets the calibration; loading weights forgets it too.
+ * Option "bias_correction" (default 1) switches the use on and off; option "bias_ready" (read only) says whether a calibration is held. */
+int keep_calibrate_bias(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, void* stream);
 int keep_get_block_precision(keep_handle* h, int block, int* attn_mode, int* mlp_mode);
 
 /* ---- preprocessing on the device -----------------------------------------------------------------

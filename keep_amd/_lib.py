@@ -38,6 +38,7 @@ SIGNATURES = {
     "keep_get_option": (C.c_double, [_vp, C.c_char_p]),
     "keep_set_block_precision": (_i32, [_vp, _i32, _i32, _i32]),
     "keep_get_block_precision": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "keep_calibrate_bias": (_i32, [_vp, _vp, _i32, _i64, _vp]),
     "keep_reserve": (_i32, [_vp, _i64, _i64, _i64]),
     "keep_workspace_bytes": (_i64, [_vp]),
     "keep_encode_image": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),

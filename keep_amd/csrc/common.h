@@ -217,6 +217,10 @@ void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const flo
                           const float* temb, const float* gamma, const float* beta, float eps,
                           int P, int T, int D, int vocab, int type_vocab,
                           float* resid, f16* out_hi, f16* out_lo /* blk layout */, int* err_flag, hipStream_t s);
+// mean-input compensation (keep_calibrate_bias): column sums of a blk-layout fp16 matrix (accumulating, deterministic), and
+// out[n] = bias[n] + sum_k w_lo[n][k] * col_sum[k] * inv_rows for a GEMM weight's lo plane
+void launch_blk_col_sum(const f16* x, int M, int K, float* out, hipStream_t s);
+void launch_bias_mean_corr(const f16* w_lo, const float* col_sum, float inv_rows, const float* bias, float* out, int N, int K, hipStream_t s);
 void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s);
 // blk-layout fp16 [*, D]: dst row r <- src row r * row_stride
 void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, int D, hipStream_t s);

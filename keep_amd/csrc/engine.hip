@@ -129,6 +129,19 @@ struct keep_handle {
     int max_tiles = 256;
     int max_prompts = 64;
     int cls_tail = 1;            // last ViT block: proj / MLP on the CLS rows only (exact; 0 = evaluate every token)
+    // Mean-input compensation of the weight-rounding error (keep_calibrate_bias).  A plain fp16 GEMM computes A_hi W_hi^T: the W_lo A_hi term it drops has
+    // a part that is the SAME for every row -- W_lo a_mean, a_mean = the mean input row of that GEMM (GELU outputs are positive, LayerNorm outputs carry their
+    // bias, attention outputs are averages) -- which no amount of averaging over tiles removes.  It is a constant vector per GEMM: folded into the bias the plain
+    // launches use.  cal[i].sum[site]: column sums of the site's input over the calibration tiles; cal[i].bias[site]: bias + W_lo a_mean.
+    struct SiteCal { float* sum[4] = {nullptr, nullptr, nullptr, nullptr}; float* bias[4] = {nullptr, nullptr, nullptr, nullptr}; double rows[4] = {0, 0, 0, 0}; };
+    std::vector<SiteCal> cal;    // per ViT block; sites: 0 qkv, 1 proj, 2 fc1, 3 fc2
+    bool capture = false;        // the running encode accumulates cal[i].sum
+    bool bias_ready = false;     // cal[i].bias hold corrected biases for the loaded weights
+    int bias_correction = 1;     // plain launches use them (0: the checkpoint's own biases)
+    void free_cal() {
+        for (auto& c : cal) for (int k = 0; k < 4; ++k) { if (c.sum[k]) (void)hipFree(c.sum[k]); if (c.bias[k]) (void)hipFree(c.bias[k]); }
+        cal.clear(); bias_ready = false;
+    }
     int cls_qkv = 1;             // last ViT block (with cls_tail): the q part of the qkv GEMM for the CLS rows only (exact; 0 = all rows)
     int proj_impl = 0;           // 2128: the plain proj GEMMs of the image tower on the 256x128 / two-workgroups-per-CU kernel (GemmParams.impl_hint); 0: the persistent 256x256 kernel
     // hipGraph replay of launch-bound calls (one prompt / one tile: ~100 dependent kernels of a few us each)
@@ -444,6 +457,15 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     hipStream_t s = L.s; VitWs& ws = L.ws;
     auto mark = [&](int stage) { if (i == 0 && L.skew_ev && L.skew_stage == stage) (void)hipEventRecord(L.skew_ev, s); };
     const VitBlock& b = h->vblocks[i];
+    // mean-input compensation: a PLAIN launch of site k uses the bias with W_lo a_mean folded in; while calibrating, every site's input is summed
+    auto site_bias = [&](int site, const float* orig, bool plain) {
+        return (plain && h->bias_ready && h->bias_correction && i < (int)h->cal.size() && h->cal[i].bias[site]) ? (const float*)h->cal[i].bias[site] : orig;
+    };
+    auto capture = [&](int site, const f16* a_hi, int rows, int K) {
+        if (!h->capture || i >= (int)h->cal.size() || !h->cal[i].sum[site]) return;
+        launch_blk_col_sum(a_hi, rows, K, h->cal[i].sum[site], s);
+        h->cal[i].rows[site] += rows;
+    };
     // Last block: everything after the attention is per-token and only the CLS token is pooled
     // (global_pool='token'), so its queries / proj / MLP are evaluated for the B CLS rows only.
     // Exact (same arithmetic on the rows that matter); the skipped FLOPs still count as algorithmic work.
@@ -477,7 +499,8 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     {
         const int tag = (sp || qkv_q) ? T_VIT_QKV_X : T_VIT_QKV;
         Scope sc(h, tag, s);
-        GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, b.qkv_b);
+        capture(0, ws.xn_hi, M, D);
+        GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, site_bias(0, b.qkv_b, !sp && !qkv_q));
         if (kv_only) {          // weight rows D .. 3D-1 (n-tiles D/256 ..), written into columns D .. 3D-1 of the token-major qkv buffer
             p.N = 2 * D; p.w_hi += (int64_t)(D / 256) * (D / 32) * 8192; p.bias += D; p.out_ld = 3 * D; p.out_col0 = D;
         }
@@ -488,7 +511,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     if (kv_only) {              // q of the CLS rows: gather their LayerNorm-1 rows, [Bc, D] x W_q^T on the small-M kernel, into a compact buffer (free until the MLP)
         Scope sc(h, T_VIT_TAIL, s);
         launch_gather_rows_blk(ws.xn_hi, 197, ws.c_xn_hi, Bc, D, s);
-        GemmParams p = gemm_params(h, ws.c_xn_hi, nullptr, b.qkv, Bc, false, b.qkv_b);
+        GemmParams p = gemm_params(h, ws.c_xn_hi, nullptr, b.qkv, Bc, false, site_bias(0, b.qkv_b, true));
         p.N = D; p.out_hi = ws.c_mlp_hi;
         if (run_gemm(h, T_VIT_TAIL, p, EPI_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-query GEMM launch failed");
     }
@@ -526,7 +549,8 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     {
         const int tag = cls_only ? T_VIT_TAIL : sp ? T_VIT_PROJ_X : T_VIT_PROJ;
         Scope sc(h, tag, s);
-        GemmParams p = gemm_params(h, att_hi, att_lo, b.proj, Mr, sp, b.proj_b);
+        capture(1, att_hi, Mr, D);
+        GemmParams p = gemm_params(h, att_hi, att_lo, b.proj, Mr, sp, site_bias(1, b.proj_b, !sp));
         p.ls = b.ls1; p.resid = resid; p.impl_hint = h->proj_impl;
         if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
         did = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
@@ -540,7 +564,8 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     {
         const int tag = cls_only ? T_VIT_TAIL : mlp ? T_VIT_FC1_X : T_VIT_FC1;
         Scope sc(h, tag, s);
-        GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, b.fc1_b);
+        capture(2, xn_hi, Mr, D);
+        GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, site_bias(2, b.fc1_b, mlp == KEEP_MLP_PLAIN));
         p.out_hi = mlp_hi; p.out_lo = mlp_lo ? mlp_lo_p : nullptr; p.out_kt = h->vit_F / 32;
         if (mlp_q) {
             p.comp = mlp_comp; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
@@ -552,7 +577,8 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     {
         const int tag = cls_only ? T_VIT_TAIL : mlp ? T_VIT_FC2_X : T_VIT_FC2;
         Scope sc(h, tag, s);
-        GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, b.fc2_b);
+        capture(3, mlp_hi, Mr, h->vit_F);
+        GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, site_bias(3, b.fc2_b, mlp == KEEP_MLP_PLAIN));
         p.ls = b.ls2; p.resid = resid;
         if (mlp_q) { p.comp = mlp_comp; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
         if (i + 1 < h->vit_depth && !cls_only) {        // next block's LayerNorm-1 reads exactly the rows written here
@@ -769,6 +795,7 @@ const WTensor* need_mat(keep_handle* h, const std::string& key, int64_t n, int64
 
 int finalize_vit(keep_handle* h) {
     h->vblocks.clear(); h->vit_depth = 0;
+    h->free_cal();               // corrected biases belong to the weights they were calibrated on
     for (float* v : h->owned_vecs) (void)hipFree(v);
     h->owned_vecs.clear();
     const WTensor* pe = find(h, "visual.patch_embed.proj.weight");
@@ -1112,6 +1139,7 @@ int keep_destroy(keep_handle* h) {
                             if (kv.second.q) hipFree(kv.second.q); if (kv.second.sc) hipFree(kv.second.sc); }
     if (h->tune.dbg) hipFree(h->tune.dbg);
     for (float* v : h->owned_vecs) hipFree(v);
+    h->free_cal();
     for (auto& l : h->blayers) { if (l.qkv.hi) hipFree(l.qkv.hi); if (l.qkv.lo) hipFree(l.qkv.lo); if (l.qkv_b) hipFree(l.qkv_b); }
     drop_graphs(h);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
@@ -1196,6 +1224,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
+    else if (n == "bias_correction") { h->bias_correction = v ? 1 : 0; }
     else if (n == "proj_impl") { if (v != 0 && v != 2128) return h->fail(KEEP_EINVAL, "proj_impl must be 0 or 2128"); h->proj_impl = v; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
     else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
@@ -1253,6 +1282,8 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "cls_tail") return h->cls_tail;
     if (n == "proj_impl") return h->proj_impl;
     if (n == "cls_qkv") return h->cls_qkv;
+    if (n == "bias_correction") return h->bias_correction;
+    if (n == "bias_ready") return h->bias_ready ? 1 : 0;
     return -1;
 }
 
@@ -1352,6 +1383,56 @@ int keep_encode_text(keep_handle* h, const int64_t* ids, const int64_t* types, c
         if (rc) return rc;
     }
     return KEEP_OK;
+}
+
+/* keep_calibrate_bias (include/keep_hip.h): mean-input compensation of the weight-rounding error, measured on the caller's tiles. */
+int keep_calibrate_bias(keep_handle* h, const void* pixels, int pix_dtype, int64_t B, void* stream) {
+    if (!h) return KEEP_EINVAL;
+    if (!h->finalized || !h->vit_depth) return h->fail(KEEP_ESTATE, "image tower not loaded / finalised");
+    if (pix_dtype < KEEP_PIX_F32 || pix_dtype > KEEP_PIX_U8_HWC) return h->fail(KEEP_EINVAL, "pixel dtype %d", pix_dtype);
+    if (B == 0) { h->bias_ready = false; ++h->opt_epoch; return KEEP_OK; }           // zero tiles: forget the calibration
+    if (!pixels || B < 8) return h->fail(KEEP_EINVAL, "bias calibration needs at least 8 tiles");
+    KEEP_ON_DEVICE(h);
+    hipStream_t s = (hipStream_t)stream;
+    ++h->opt_epoch;
+    const int D = h->vit_D, F = h->vit_F;
+    const int widths[4] = {D, D, D, F}, outs[4] = {3 * D, D, F, D};
+    if ((int)h->cal.size() != h->vit_depth) {
+        h->free_cal();
+        h->cal.resize(h->vit_depth);
+        for (auto& c : h->cal)
+            for (int k = 0; k < 4; ++k) {
+                HIPCHK(h, hipMalloc(&c.sum[k], widths[k] * sizeof(float)));
+                HIPCHK(h, hipMalloc(&c.bias[k], outs[k] * sizeof(float)));
+            }
+    }
+    for (auto& c : h->cal)
+        for (int k = 0; k < 4; ++k) { HIPCHK(h, hipMemsetAsync(c.sum[k], 0, widths[k] * sizeof(float), s)); c.rows[k] = 0; }
+    h->bias_ready = false;
+    float* scratch = nullptr;
+    HIPCHK(h, hipMalloc(&scratch, (size_t)B * h->proj_dim * sizeof(float)));
+    // one lane, no graph replay: every site is visited once per sub-batch, on ONE stream, so the sums accumulate in a fixed order
+    const int streams_was = h->n_streams, graphs_was = h->use_graphs, prec_was = h->precision;
+    h->n_streams = 1; h->use_graphs = 0; h->precision = KEEP_PREC_STRICT; h->capture = true;      // split products: the cleanest activations to average
+    int rc = encode_image_run(h, pixels, pix_dtype, B, scratch, s);
+    h->n_streams = streams_was; h->use_graphs = graphs_was; h->precision = prec_was; h->capture = false;
+    if (!rc) {
+        for (int i = 0; i < h->vit_depth && !rc; ++i) {
+            const VitBlock& b = h->vblocks[i];
+            const WTensor* w[4] = {b.qkv, b.proj, b.fc1, b.fc2};
+            const float* bias[4] = {b.qkv_b, b.proj_b, b.fc1_b, b.fc2_b};
+            for (int k = 0; k < 4; ++k) {
+                if (!w[k]->lo || !(h->cal[i].rows[k] > 0)) { rc = h->fail(KEEP_ESTATE, "block %d site %d was not visited by the calibration encode", i, k); break; }
+                launch_bias_mean_corr(w[k]->lo, h->cal[i].sum[k], (float)(1.0 / h->cal[i].rows[k]), bias[k], h->cal[i].bias[k], outs[k], widths[k], s);
+            }
+        }
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (rc) return rc;
+    HIPCHK(h, e);
+    h->bias_ready = true;
+    return check_launch(h, "calibrate_bias");
 }
 
 int keep_resize_crop_u8(keep_handle* h, const unsigned char* src, int64_t B, int64_t H, int64_t W, const int32_t* xbounds, const int32_t* xweights,

@@ -499,6 +499,50 @@ __global__ void gather_rows_blk_kernel(const f16* __restrict__ src, int row_stri
 }  // namespace keepk
 using namespace keepk;
 
+// ------------------------------------------------------------------ mean-input compensation (keep_calibrate_bias)
+// out[k] += sum over rows m < M of x[m][k]  (x in blk layout; out zeroed by the caller).  One workgroup owns one 32-column K slice and walks
+// every row tile in a fixed order: no atomics, the sums are bit-reproducible (launches on ONE stream accumulate in issue order)
+__global__ __launch_bounds__(256)
+void blk_col_sum_kernel(const f16* __restrict__ x, int M, int KT, float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int kt = blockIdx.x, k = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int tiles = (M + 255) >> 8;
+    float acc = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        const f16* base = x + ((int64_t)t * KT + kt) * 8192 + k;
+        const int rows = (M - t * 256) < 256 ? (M - t * 256) : 256;
+        for (int r = rg; r < rows; r += 8) acc += (float)base[r * 32];
+    }
+    red[rg][k] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += red[g][k];
+        out[kt * 32 + k] += v;
+    }
+}
+void launch_blk_col_sum(const f16* x, int M, int K, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(blk_col_sum_kernel, dim3(K / 32), dim3(256), 0, s, x, M, K / 32, out);
+}
+
+// out[n] = bias[n] + sum_k w_lo[n][k] * (col_sum[k] * inv_rows)     (w_lo: the lo plane of a GEMM weight, blk layout [N][K]; one wave per row)
+__global__ __launch_bounds__(256)
+void bias_mean_corr_kernel(const f16* __restrict__ w_lo, const float* __restrict__ col_sum, float inv_rows, const float* __restrict__ bias,
+                           float* __restrict__ out, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const int KT = K / 32;
+    const f16* row = w_lo + (int64_t)(n >> 8) * KT * 8192 + (n & 255) * 32;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += (float)row[(int64_t)(k >> 5) * 8192 + (k & 31)] * col_sum[k];
+    acc = wave_sum(acc);
+    if (lane == 0) out[n] = bias[n] + acc * inv_rows;
+}
+void launch_bias_mean_corr(const f16* w_lo, const float* col_sum, float inv_rows, const float* bias, float* out, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(bias_mean_corr_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w_lo, col_sum, inv_rows, bias, out, N, K);
+}
+
 void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, int D, hipStream_t s) {
     const int64_t n = (int64_t)rows * (D / 8);
     hipLaunchKernelGGL(gather_rows_blk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, row_stride, dst, rows, D);

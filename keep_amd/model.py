@@ -169,6 +169,9 @@ class KEEPModel:
         # (about 2 s at load for ViT-L); "ladder": the prefix family COMP_LADDER only (under 1 s, up to 12 % slower plans -- profiles/r05_precision_budget.md)
         self.calibration_budget = os.environ.get("KEEP_CALIBRATION_BUDGET", "measured")
         self.calibration: Optional[dict] = None
+        # load_state_dict on a GPU also runs calibrate_bias(): the mean-input compensation of the weight-rounding error that the plain fp16 launches use
+        # (keep_calibrate_bias; KEEP_BIAS_CORRECTION=0 / bias_correction=False: the checkpoint's own biases everywhere)
+        self.bias_correction = os.environ.get("KEEP_BIAS_CORRECTION", "1") != "0"
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
 
@@ -307,8 +310,11 @@ class KEEPModel:
         self._loaded = True
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1      # invalidates per-model prompt caches (keep_amd.wsi)
         self.calibration = None
-        if self.auto_calibrate and self._options["precision"] == _lib.PREC_COMP and lib.keep_vit_depth(h) > 0:
-            self.calibrate()
+        if self.auto_calibrate and lib.keep_vit_depth(h) > 0:
+            if self.bias_correction and self._options["precision"] != _lib.PREC_STRICT:
+                self.calibrate_bias()
+            if self._options["precision"] == _lib.PREC_COMP:
+                self.calibrate()
 
     @classmethod
     def from_pretrained(cls, path: str, precision: str = DEFAULT_PRECISION, **_ignored) -> "KEEPModel":
@@ -381,6 +387,26 @@ class KEEPModel:
             _lib.check(h, lib.keep_get_block_precision(h, i, C.byref(a), C.byref(m)), "get_block_precision")
             out.append((a.value, m.value))
         return out
+
+    @torch.no_grad()
+    def calibrate_bias(self, tiles: Optional[torch.Tensor] = None, n_tiles: int = 64, seed: int = 20250936) -> "KEEPModel":
+        """Mean-input compensation of the weight-rounding error (``keep_calibrate_bias``): the engine encodes ``tiles`` (default ``n_tiles`` seeded N(0,1)
+        tiles; pass tiles of the caller's own distribution for a closer mean) in split products, averages the input rows of every GEMM of the image
+        tower and folds ``W_lo @ mean_input`` into the bias its plain fp16 launches use -- the row-independent part of the term a single fp16 pass drops,
+        10-50 % of a GEMM's weight-rounding variance, at no cost per call.  ``tiles`` of zero length forgets the calibration."""
+        self._ready()
+        dev = self._device
+        if tiles is None:
+            g = torch.Generator(device=dev).manual_seed(seed)
+            tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+        x = tiles.to(dev)
+        if x.dtype not in _PIX and x.dtype != torch.uint8:
+            x = x.to(torch.float32)
+        x = x.contiguous()
+        code = _lib.PIX_U8_HWC if x.dtype == torch.uint8 else _PIX[x.dtype]
+        _lib.check(self._handle, _lib.load().keep_calibrate_bias(self._handle, _ptr(x) if x.shape[0] else C.c_void_p(0), code, x.shape[0], _stream(dev)), "calibrate_bias")
+        self._weights_epoch = getattr(self, "_weights_epoch", 0)      # (text features do not depend on it: the prompt caches stay valid)
+        return self
 
     @torch.no_grad()
     def calibrate(self, n_tiles: int = 256, population: Optional[float] = None, tiles: Optional[torch.Tensor] = None,
@@ -499,7 +525,8 @@ class KEEPModel:
                             "population": population, "confidence": confidence, "max_sigmas_quantile": round(z_pop, 3),
                             "expected_max_sigmas": round(expected_max_sigmas(population), 3),
                             "target_rms_dcos": float(f"{rms_target:.3e}"), "strict_blocks": strict_blocks,
-                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts vs the split-product arithmetic", "tried": tried}
+                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts vs the split-product arithmetic", "tried": tried,
+                            "bias_correction": bool(lib.keep_get_option(h, b"bias_ready") > 0 and lib.keep_get_option(h, b"bias_correction") > 0)}
         if chosen:
             err, rms, pred, tail = chosen_stats
             # keep_classify looks a second time at tiles whose top-2 cosine margin could hide a flipped label.  A margin is the difference of two

@@ -166,8 +166,10 @@ def test_long_and_single_inputs(small, text_bank):
         refr = O.encode_text(small, rag)
     assert (ms.encode_text(rag) @ text_bank.t() - refr @ text_bank.t()).abs().max() < 5e-6
     assert (mc.encode_text(rag) @ text_bank.t() - refr @ text_bank.t()).abs().max() < COS_TOL
+    too_long = synth_prompts(1, 513, seed=20)
+    too_long["attention_mask"][:] = 1                        # (otherwise the padding trim shortens the call)
     with pytest.raises(ValueError):
-        ms.encode_text(synth_prompts(1, 513, seed=20))
+        ms.encode_text(too_long)
 
 
 def test_forward_and_errors(small):
@@ -854,6 +856,52 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
         assert lib.keep_set_block_precision(m._handle, *bad) == _lib.KEEP_EINVAL
     with pytest.raises(ValueError):
         m.set_plan([(0, 7)])
+
+
+def test_mean_input_bias_compensation():
+    """keep_calibrate_bias: the row-independent part of the dropped W_lo A_hi term (W_lo @ mean input row) folded into the bias of the plain fp16
+    launches.  Full depth, bench weights, everything plain: with the compensation the cosine errors against the split-product mode are smaller than
+    without (the CPU study behind it: 8 % of the all-fp16 variance, 25 % of its weight-rounding half); it is held per handle, forgotten on request
+    and on reload, switched by an option, and split / compensated launches never see it."""
+    sd = synth_state_dict(KEEPShape(), seed=0, text=False)
+    m = KEEPModel(KEEPShape(), precision="comp", towers=("image",))
+    m.auto_calibrate = False
+    m.load_state_dict(sd, strict=True)
+    m.to("cuda:0")
+    assert m.get_option("bias_ready") == 0                        # nothing calibrated yet (auto_calibrate off)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(128, 3, 224, 224, generator=g).to(torch.bfloat16).cuda()
+    bank = torch.nn.functional.normalize(torch.randn(64, 768, generator=g), dim=-1).cuda()
+    m.set_precision("strict")
+    ref = m.similarity(m.encode_image(x), bank)
+    m.set_precision("comp")
+    m.set_plan([(0, 0)] * 24)
+    off = m.similarity(m.encode_image(x), bank)
+    m.calibrate_bias()
+    assert m.get_option("bias_ready") == 1 and m.get_option("bias_correction") == 1
+    on = m.similarity(m.encode_image(x), bank)
+    rms = lambda d: float(d.pow(2).mean().sqrt())
+    print(f"[bias compensation] all-plain plan, 128 tiles x 64 random directions vs split products: rms {rms(off - ref):.3e} -> {rms(on - ref):.3e} "
+          f"(variance x{(rms(on - ref) / rms(off - ref)) ** 2:.3f})")
+    assert rms(on - ref) < 0.99 * rms(off - ref)
+    m.set_option("bias_correction", 0)
+    assert torch.equal(m.similarity(m.encode_image(x), bank), off)                 # switched off: the checkpoint's biases, bit for bit
+    m.set_option("bias_correction", 1)
+    assert torch.equal(m.similarity(m.encode_image(x), bank), on)                  # deterministic
+    m.calibrate_bias(); assert torch.equal(m.similarity(m.encode_image(x), bank), on)      # and reproducible: no atomics in the averages
+    # split / compensated launches compute the W_lo term themselves: the all-split plan does not change
+    m.set_plan([(1, 1)] * 24)
+    sp_on = m.encode_image(x[:32])
+    m.calibrate_bias(x[:0])                                                        # zero tiles: forget
+    assert m.get_option("bias_ready") == 0 and torch.equal(m.encode_image(x[:32]), sp_on)
+    m.set_plan([(0, 0)] * 24)
+    assert torch.equal(m.similarity(m.encode_image(x), bank), off)
+    with pytest.raises(ValueError):
+        m.calibrate_bias(x[:3])                                                    # too few tiles to average
+    m.calibrate_bias(x)                                                            # the caller's own tiles are accepted
+    assert rms(m.similarity(m.encode_image(x), bank) - ref) < 0.99 * rms(off - ref)
+    m.load_state_dict(sd, strict=True)                                             # reload: calibrations belong to the weights
+    assert m.get_option("bias_ready") == 0
 
 
 def test_fp16_range_of_the_qkv_and_hidden_stores(small, text_bank):
