@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--tiles", type=int, default=256)
     ap.add_argument("--skip-cost", action="store_true")
     ap.add_argument("--family", default="default")
+    ap.add_argument("--no-bias", action="store_true", help="without the mean-input bias compensation (keep_calibrate_bias) the product applies at load")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -52,6 +53,8 @@ def main():
     m.load_state_dict(synth_state_dict(shape, seed=0, family=args.family))
     m.to(dev).eval()
     m.reserve(tiles=256)
+    if not args.no_bias:
+        m.calibrate_bias()
     depth = shape.vision.depth
     g = torch.Generator(device=dev).manual_seed(20250929)
     tiles = torch.randn(args.tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
@@ -195,7 +198,7 @@ def main():
                 verify(f"  ... tightened", plan2)
     if not args.skip_cost:
         base_ms.append(ms_of(plain_all))
-    out = {"probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts, bench weights (family {args.family})", "all_plain_rms": total ** 0.5, "floor_rms": floor ** 0.5,
+    out = {"probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts, bench weights (family {args.family}), mean-input bias compensation {'off' if args.no_bias else 'on'}", "all_plain_rms": total ** 0.5, "floor_rms": floor ** 0.5,
            "variance_share_of_all_plain": {k: [v / total for v in vs] for k, vs in var.items()}, "variance_abs": var,
            "plain_ms_per_step": base_ms, "cost_samples_ms": {k: {str(b): v for b, v in d.items()} for k, d in cost.items()}, "per_block_cost_ms": per_block_ms,
            "targets_rms": targets, "plans": results}
