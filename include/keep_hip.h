@@ -77,8 +77,12 @@ enum {
     KEEP_MLP_PLAIN = 0,           /* fc1 / fc2: single fp16 passes                                                                  */
     KEEP_MLP_SPLIT = 1,           /* split products (three fp16 passes)                                                             */
     KEEP_MLP_COMP = 2,            /* compensated: fp16 pass + both first-order terms W_lo A_hi + W_hi A_lo on the MX-fp4 pipe       */
-    KEEP_MLP_COMP_W = 3           /* compensated, weight-rounding term W_lo A_hi only (half the fp4 MFMAs and operand bytes; the    */
+    KEEP_MLP_COMP_W = 3,          /* compensated, weight-rounding term W_lo A_hi only (half the fp4 MFMAs and operand bytes; the    */
                                   /* LayerNorm / GELU epilogues write Q(x_hi) only): removes the W half of the fp16 rounding error  */
+    KEEP_MLP_CLS = 4              /* single fp16 passes for every row, then the CLS row of every tile AGAIN as split products: B rows */
+                                  /* through LayerNorm-2 -> fc1 -> GELU -> fc2 on the small-M kernels, written over the fp16 result.  */
+                                  /* The pooled output IS the CLS row (global_pool='token', keep_inference.py:32-40): its own rounding */
+                                  /* errors reach the feature directly, the other 196 rows' only through attention averages          */
 };
 
 const char* keep_version(void);
@@ -286,7 +290,7 @@ int keep_op_linear(keep_handle* h, const float* a, const float* w, const float* 
                    void* stream);
 /* One MLP half of a ViT block through the tower's own kernels (timm Block: x + ls2 * fc2(gelu(fc1(norm2(x))))):
  *   LayerNorm (writes the fp16 operand and, per mode, its lo plane / MX-fp4 side planes) -> fc1 + GELU -> fc2 + LayerScale + residual.
- *   mode = KEEP_MLP_*: 0 plain fp16 | 1 split | 2 compensated | 3 compensated, W_lo term only.  x, out fp32 [M, D]; D in {768, 1024}; F % 256 == 0. */
+ *   mode = KEEP_MLP_* 0..3: 0 plain fp16 | 1 split | 2 compensated | 3 compensated, W_lo term only.  x, out fp32 [M, D]; D in {768, 1024}; F % 256 == 0. */
 int keep_op_mlp(keep_handle* h, const float* x, const float* ln_w, const float* ln_b, const float* fc1_w, const float* fc1_b,
                 const float* fc2_w, const float* fc2_b, const float* ls, int64_t M, int64_t D, int64_t F, int mode, float* out,
                 void* stream);

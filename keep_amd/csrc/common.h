@@ -222,6 +222,7 @@ void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const flo
 void launch_blk_col_sum(const f16* x, int M, int K, float* out, hipStream_t s);
 void launch_bias_mean_corr(const f16* w_lo, const float* col_sum, float inv_rows, const float* bias, float* out, int N, int K, hipStream_t s);
 void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s);
+void launch_scatter_rows_f32(const float* src, float* dst, int64_t dst_stride, int rows, int D, hipStream_t s);   // dst row r * dst_stride <- src row r
 // blk-layout fp16 [*, D]: dst row r <- src row r * row_stride
 void launch_gather_rows_blk(const f16* src, int row_stride, f16* dst, int rows, int D, hipStream_t s);
 

@@ -109,7 +109,8 @@ struct keep_handle {
     // The per-block plan of KEEP_PREC_COMP (keep_set_block_precision; the four options above are prefix shorthands that rewrite it):
     //   attn_mode[i]  attention side of block i: KEEP_ATTN_PLAIN | KEEP_ATTN_SPLIT (qkv, q/k/v storage, attention, proj as split products) |
     //                 KEEP_ATTN_SPLIT_COMPQKV (the same with the qkv GEMM as a compensated product) | KEEP_ATTN_COMPQKV (compensated qkv only)
-    //   mlp_mode[i]   fc1 / fc2 of block i: KEEP_MLP_PLAIN | KEEP_MLP_SPLIT | KEEP_MLP_COMP (both MX-fp4 correction terms) | KEEP_MLP_COMP_W (the W_lo term only)
+    //   mlp_mode[i]   fc1 / fc2 of block i: KEEP_MLP_PLAIN | KEEP_MLP_SPLIT | KEEP_MLP_COMP (both MX-fp4 correction terms) | KEEP_MLP_COMP_W (the W_lo term only) |
+    //                 KEEP_MLP_CLS (plain for every row + the CLS rows again as split products)
     // Which block gets what is a measured, per-checkpoint decision (tools/precision_budget.py, KEEPModel.calibrate).
     static constexpr int MAX_BLOCKS = 64;
     unsigned char attn_mode[MAX_BLOCKS] = {}, mlp_mode[MAX_BLOCKS] = {};
@@ -197,12 +198,14 @@ struct keep_handle {
         const int a = plan_attn(i);
         return a == KEEP_ATTN_SPLIT_COMPQKV || a == KEEP_ATTN_COMPQKV;
     }
-    // fc1 / fc2 of block i: 0 plain | 1 split (three fp16 passes) | 2 compensated (both MX-fp4 terms) | 3 compensated, W_lo term only
+    // fc1 / fc2 of block i: 0 plain | 1 split (three fp16 passes) | 2 compensated (both MX-fp4 terms) | 3 compensated, W_lo term only | 4 plain + CLS rows split
+    // (lane_tiles == 0: the last block's CLS-rows-only tail, which is the "CLS rows as split products" half on its own)
     int vit_mlp_mode(int i, int lane_tiles) const {
         if (precision == KEEP_PREC_STRICT || i < strict_blocks) return KEEP_MLP_SPLIT;
         if (precision != KEEP_PREC_COMP || i < 0 || i >= MAX_BLOCKS) return KEEP_MLP_PLAIN;
         const int m = mlp_mode[i];
         if (m == KEEP_MLP_COMP || m == KEEP_MLP_COMP_W) return (lane_tiles >= comp_min_tiles && vit_has_q) ? m : KEEP_MLP_SPLIT;
+        if (m == KEEP_MLP_CLS) return lane_tiles == 0 ? KEEP_MLP_SPLIT : KEEP_MLP_CLS;
         return m;
     }
     // the text tower is 1 % of a slide's work: in the compensated mode it simply runs split products throughout, at every length BertModel accepts
@@ -213,7 +216,7 @@ struct keep_handle {
     bool any_comp() const {
         if (precision != KEEP_PREC_COMP || !vit_has_q) return false;
         for (int i = 0; i < MAX_BLOCKS && i < (vit_depth ? vit_depth : MAX_BLOCKS); ++i)
-            if (mlp_mode[i] >= KEEP_MLP_COMP || attn_mode[i] >= KEEP_ATTN_SPLIT_COMPQKV) return true;
+            if (mlp_mode[i] == KEEP_MLP_COMP || mlp_mode[i] == KEEP_MLP_COMP_W || attn_mode[i] >= KEEP_ATTN_SPLIT_COMPQKV) return true;
         return false;
     }
 
@@ -474,6 +477,8 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     const int mlp = h->vit_mlp_mode(i, cls_only ? 0 : Bc);             // fc1 / fc2: 0 plain, 1 split, 2 compensated (both MX-fp4 terms), 3 compensated (W_lo term only)
     const bool mlp_lo = mlp == KEEP_MLP_SPLIT, mlp_q = mlp == KEEP_MLP_COMP || mlp == KEEP_MLP_COMP_W;
     const int mlp_comp = mlp == KEEP_MLP_COMP_W ? 1 : 2;               // GemmParams.comp of the block's fc1 / fc2
+    const bool mlp_cls = mlp == KEEP_MLP_CLS;                          // every row plain, then the CLS rows again as split products (below)
+    const bool mlp_plain = mlp == KEEP_MLP_PLAIN || mlp_cls;
 #ifdef KEEP_DIAGNOSTICS
     const bool skip_ln = h->dbg_skip_ln == 1 && h->dbg_calls > 3;
 #else
@@ -557,15 +562,19 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
     }
     mark(3);
+    if (mlp_cls) {              // the CLS rows' residual as it enters the MLP (the plain fc2 below updates these rows too; the split result replaces that)
+        Scope sc(h, T_VIT_TAIL, s);
+        launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
+    }
     if (!(did & GEMM_DID_LN) && !skip_ln) {
         Scope sc(h, T_VIT_LN, s);
         if (launch_layernorm(ln, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
     }
     {
-        const int tag = cls_only ? T_VIT_TAIL : mlp ? T_VIT_FC1_X : T_VIT_FC1;
+        const int tag = cls_only ? T_VIT_TAIL : !mlp_plain ? T_VIT_FC1_X : T_VIT_FC1;
         Scope sc(h, tag, s);
         capture(2, xn_hi, Mr, D);
-        GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, site_bias(2, b.fc1_b, mlp == KEEP_MLP_PLAIN));
+        GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, site_bias(2, b.fc1_b, mlp_plain));
         p.out_hi = mlp_hi; p.out_lo = mlp_lo ? mlp_lo_p : nullptr; p.out_kt = h->vit_F / 32;
         if (mlp_q) {
             p.comp = mlp_comp; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
@@ -575,13 +584,13 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     }
     mark(4);
     {
-        const int tag = cls_only ? T_VIT_TAIL : mlp ? T_VIT_FC2_X : T_VIT_FC2;
+        const int tag = cls_only ? T_VIT_TAIL : !mlp_plain ? T_VIT_FC2_X : T_VIT_FC2;
         Scope sc(h, tag, s);
         capture(3, mlp_hi, Mr, h->vit_F);
-        GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, site_bias(3, b.fc2_b, mlp == KEEP_MLP_PLAIN));
+        GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, site_bias(3, b.fc2_b, mlp_plain));
         p.ls = b.ls2; p.resid = resid;
         if (mlp_q) { p.comp = mlp_comp; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
-        if (i + 1 < h->vit_depth && !cls_only) {        // next block's LayerNorm-1 reads exactly the rows written here
+        if (i + 1 < h->vit_depth && !cls_only && !mlp_cls) {        // next block's LayerNorm-1 reads exactly the rows written here (not when CLS rows are still to be replaced)
             const VitBlock& nb = h->vblocks[i + 1];
             ln.x = ws.resid; ln.rows = M; ln.out_hi = ws.xn_hi; ln.out_lo = h->vit_attn_split(i + 1, Bc) ? ws.xn_lo : nullptr;
             ln.out_q = nullptr; ln.out_sc = nullptr; ln.out_q_hi_only = 0;
@@ -591,6 +600,23 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         const int rc = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
         if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "fc2 GEMM launch failed");
         L.xn_ready = (rc & GEMM_DID_LN) != 0;
+    }
+    if (mlp_cls) {
+        // The CLS row of every tile once more, as split products on the small-M kernels: LayerNorm-2 -> fc1 + GELU -> fc2 + LayerScale + residual on the
+        // compact [Bc, D] copy taken after proj, then written over the rows the plain fc2 produced.  0.5 % of the rows; the feature is pooled from them.
+        Scope sc(h, T_VIT_TAIL, s);
+        LnParams cl{};
+        cl.tune = &h->tune;
+        cl.x = ws.c_resid; cl.x_stride = D; cl.rows = Bc; cl.D = D; cl.eps = 1e-6f; cl.gamma = b.n2w; cl.beta = b.n2b;
+        cl.out_hi = ws.c_xn_hi; cl.out_lo = ws.c_xn_lo; cl.out_kt = D / 32;
+        if (launch_layernorm(cl, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
+        GemmParams p = gemm_params(h, ws.c_xn_hi, ws.c_xn_lo, b.fc1, Bc, true, b.fc1_b);
+        p.out_hi = ws.c_mlp_hi; p.out_lo = ws.c_mlp_lo; p.out_kt = h->vit_F / 32;
+        if (run_gemm(h, T_VIT_TAIL, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc1 GEMM launch failed");
+        GemmParams r = gemm_params(h, ws.c_mlp_hi, ws.c_mlp_lo, b.fc2, Bc, true, b.fc2_b);
+        r.ls = b.ls2; r.resid = ws.c_resid;
+        if (run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc2 GEMM launch failed");
+        launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
     }
     mark(5);
     return KEEP_OK;
@@ -1290,7 +1316,7 @@ double keep_get_option(keep_handle* h, const char* name) {
 int keep_set_block_precision(keep_handle* h, int block, int attn_mode, int mlp_mode) {
     if (!h) return KEEP_EINVAL;
     if (block < 0 || block >= keep_handle::MAX_BLOCKS) return h->fail(KEEP_EINVAL, "block %d outside 0..%d", block, keep_handle::MAX_BLOCKS - 1);
-    if (attn_mode > KEEP_ATTN_COMPQKV || mlp_mode > KEEP_MLP_COMP_W) return h->fail(KEEP_EINVAL, "attn_mode %d / mlp_mode %d (0..3, negative = leave)", attn_mode, mlp_mode);
+    if (attn_mode > KEEP_ATTN_COMPQKV || mlp_mode > KEEP_MLP_CLS) return h->fail(KEEP_EINVAL, "attn_mode %d (0..3) / mlp_mode %d (0..4); negative = leave", attn_mode, mlp_mode);
     ++h->opt_epoch;               // captured graphs bake the plan in
     if (attn_mode >= 0) h->attn_mode[block] = (unsigned char)attn_mode;
     if (mlp_mode >= 0) h->mlp_mode[block] = (unsigned char)mlp_mode;

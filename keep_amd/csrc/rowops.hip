@@ -488,6 +488,13 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_st
     dst[i] = src[(int64_t)r * src_stride + d];
 }
 
+__global__ void scatter_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t dst_stride, int rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * D) return;
+    const int r = (int)(i / D), d = (int)(i % D);
+    dst[(int64_t)r * dst_stride + d] = src[i];
+}
+
 __global__ void gather_rows_blk_kernel(const f16* __restrict__ src, int row_stride, f16* __restrict__ dst, int rows, int D) {
     const int KT = D / 32;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 16-byte chunk (8 k) per thread
@@ -651,6 +658,10 @@ void launch_bert_embed_ln(const int64_t* ids, const int64_t* type_ids, const flo
     else
         hipLaunchKernelGGL(bert_embed_ln_kernel<1>, grid, block, 0, s, ids, type_ids, wemb, pemb, temb, gamma, beta, eps,
                            rows, T, vocab, type_vocab, resid, out_hi, out_lo, err_flag);
+}
+void launch_scatter_rows_f32(const float* src, float* dst, int64_t dst_stride, int rows, int D, hipStream_t s) {
+    const int64_t n = (int64_t)rows * D;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, dst_stride, rows, D);
 }
 void launch_gather_rows_f32(const float* src, int64_t src_stride, float* dst, int rows, int D, hipStream_t s) {
     const int64_t n = (int64_t)rows * D;

@@ -42,15 +42,18 @@ CONFIDENCE = 0.99
 PROBE_RMS_MARGIN = 1.02
 # Milliseconds a knob adds to a 256-tile encode step on an MI355X (two lanes; tools/precision_budget.py measures them, profiles/r05_precision_budget.md):
 # what the greedy of budget="measured" divides a knob's variance share by.  Only the RATIOS matter.
-KNOB_COST_MS = {"attn_split": 0.96, "attn_split_compqkv": 0.59, "attn_compqkv": 0.22, "mlp_comp": 0.53, "mlp_comp_w": 0.30}
+KNOB_COST_MS = {"attn_split": 0.93, "attn_split_compqkv": 0.57, "attn_compqkv": 0.24, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.05}
 # Share of a site's rounding variance that survives a treatment when it is not measured on the loaded weights (same tool, bench weights): both
 # MX-fp4 correction terms remove ~96 % of an MLP's share, the W_lo term alone 40-55 %; a compensated qkv inside a split attention side leaves 1-2 %
-MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}
+MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_CLS: 0.1, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}
 ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_SPLIT_COMPQKV: 0.015, _lib.ATTN_SPLIT: 0.0}
 # The treatments the greedy of budget="measured" may use.  Measured on the bench weights (profiles/r05_precision_budget.md): the W_lo-only MLP form
 # removes ~45 % of a block's MLP share for 57 % of the cost of both terms, and a compensated qkv alone ~35 % of an attention side's share at 1 ms per
 # percent of variance against 0.45 for MLP blocks -- neither ever wins a greedy step, so they are off by default (``knobs=`` switches them on).
-DEFAULT_KNOBS = {"attn": (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_COMP,)}
+# KEEP_MLP_CLS (every row plain, the CLS row of every tile again as split products) is the cheap one: the feature is pooled from the CLS rows, whose
+# own rounding errors reach it directly while the other 196 rows' only arrive through attention averages -- what it leaves of a block's MLP share is
+# measured per block (4-6 % outside the first block on the bench weights, 25-30 % in block 0).
+DEFAULT_KNOBS = {"attn": (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_CLS, _lib.MLP_COMP)}
 
 Plan = List[Tuple[int, int]]
 
@@ -362,8 +365,8 @@ class KEEPModel:
         """The per-block plan of the 'comp' mode: ``plan[i] = (attention-side mode, MLP mode)`` of ViT block i (``_lib.ATTN_*`` / ``_lib.MLP_*``,
         = KEEP_ATTN_* / KEEP_MLP_* of include/keep_hip.h).  Blocks beyond ``len(plan)`` run plain fp16 passes."""
         plan = [(int(a), int(m)) for a, m in plan]
-        if any(not (0 <= a <= 3 and 0 <= m <= 3) for a, m in plan) or len(plan) > 64:
-            raise ValueError("a plan holds at most 64 (attn_mode, mlp_mode) pairs with modes 0..3")
+        if any(not (0 <= a <= 3 and 0 <= m <= 4) for a, m in plan) or len(plan) > 64:
+            raise ValueError("a plan holds at most 64 (attn_mode 0..3, mlp_mode 0..4) pairs")
         pre = plan_prefix(plan)
         for k in self._PLAN_SHORTHANDS:
             self._options.pop(k, None)
@@ -560,6 +563,9 @@ class KEEPModel:
         attn = [max(var_of(i, (_lib.ATTN_PLAIN, _lib.MLP_SPLIT)) - floor, 0.0) for i in range(depth)]
         mlp = [max(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_PLAIN)) - floor, 0.0) for i in range(depth)]
         res_m, res_a = dict(MLP_RESIDUAL), dict(ATTN_RESIDUAL)
+        # what the CLS-rows-only treatment leaves differs from block to block (most in the first, where every row's error is amplified by all the
+        # attention layers that follow): measured for every block
+        cls_left = [min(max(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_CLS)) - floor, 0.0) / mlp[i], 1.0) if mlp[i] > 0 else 0.0 for i in range(depth)]
         for mode in (_lib.MLP_COMP, _lib.MLP_COMP_W):
             fr = [max(var_of(i, (_lib.ATTN_SPLIT, mode)) - floor, 0.0) / mlp[i] for i in sorted({0, depth // 2}) if mlp[i] > 0]
             if fr:
@@ -568,7 +574,8 @@ class KEEPModel:
             if attn[0] > 0:
                 res_a[mode] = min(max(var_of(0, (mode, _lib.MLP_SPLIT)) - floor, 0.0) / attn[0], 1.0)
         attn, mlp, floor = [float(f"{v:.3e}") for v in attn], [float(f"{v:.3e}") for v in mlp], float(f"{floor:.3e}")
-        return {"attn": attn, "mlp": mlp, "floor": floor, "residual_mlp": {int(k): float(f"{v:.4f}") for k, v in res_m.items()},
+        res_m[_lib.MLP_CLS] = [float(f"{v:.4f}") for v in cls_left]
+        return {"attn": attn, "mlp": mlp, "floor": floor, "residual_mlp": {int(k): (v if isinstance(v, list) else float(f"{v:.4f}")) for k, v in res_m.items()},
                 "residual_attn": {int(k): float(f"{v:.4f}") for k, v in res_a.items()}, "probe_tiles": int(tiles.shape[0])}
 
     @staticmethod
@@ -576,14 +583,17 @@ class KEEPModel:
         """[(plan, predicted cosine-error variance)] from the all-plain plan upwards: every step takes the ONE upgrade (a block's attention side or
         MLP to one of the allowed treatments) with the largest predicted variance reduction per millisecond (KNOB_COST_MS); the last entry has
         every site at its best allowed treatment."""
-        res_a, res_m = shares["residual_attn"], shares["residual_mlp"]
+        res_a = {int(k): v for k, v in shares["residual_attn"].items()}
+        res_m_raw = {int(k): v for k, v in shares["residual_mlp"].items()}
+        left_m = lambda i, mode: (res_m_raw[mode][i] if isinstance(res_m_raw[mode], (list, tuple)) else res_m_raw[mode])
         cost_a = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"], _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"],
                   _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
-        cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"], _lib.MLP_SPLIT: 3.0 * KNOB_COST_MS["mlp_comp"]}
+        cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_CLS: KNOB_COST_MS["mlp_cls"], _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"],
+                  _lib.MLP_SPLIT: 3.0 * KNOB_COST_MS["mlp_comp"]}
         am, mm = [_lib.ATTN_PLAIN] * depth, [_lib.MLP_PLAIN] * depth
 
         def predicted():
-            return shares["floor"] + sum(shares["attn"][i] * res_a[am[i]] + shares["mlp"][i] * res_m[mm[i]] for i in range(depth))
+            return shares["floor"] + sum(shares["attn"][i] * res_a[am[i]] + shares["mlp"][i] * left_m(i, mm[i]) for i in range(depth))
 
         walk = [(list(zip(am, mm)), predicted())]
         while True:
@@ -594,7 +604,7 @@ class KEEPModel:
                     if dc > 0 and dv > 0 and dv / dc > gain:
                         best, gain = (am, i, a), dv / dc
                 for m in knobs.get("mlp", ()):
-                    dc, dv = cost_m[m] - cost_m[mm[i]], shares["mlp"][i] * (res_m[mm[i]] - res_m[m])
+                    dc, dv = cost_m[m] - cost_m[mm[i]], shares["mlp"][i] * (left_m(i, mm[i]) - left_m(i, m))
                     if dc > 0 and dv > 0 and dv / dc > gain:
                         best, gain = (mm, i, m), dv / dc
             if best is None:

@@ -835,8 +835,8 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     assert e_split < 0.05 * e_plain
     got = {}
     for name, plan in {"mlp comp": [(0, 2)] * depth, "mlp comp, W_lo term": [(0, 3)] * depth, "attn split": [(1, 0)] * depth,
-                       "attn split, comp qkv": [(2, 0)] * depth, "comp qkv only": [(3, 0)] * depth,
-                       "mixed": [(1, 2), (3, 3), (0, 3), (2, 0)]}.items():
+                       "attn split, comp qkv": [(2, 0)] * depth, "comp qkv only": [(3, 0)] * depth, "mlp plain + CLS rows split": [(0, 4)] * depth,
+                       "mixed": [(1, 2), (3, 3), (0, 4), (2, 0)]}.items():
         m.set_plan(plan)
         assert m.get_plan() == plan and (m.get_option("plan_custom") == 1 or plan_prefix(plan) is not None)
         got[name] = err(m.encode_image(x))
@@ -844,15 +844,24 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     print(f"[plans, depth {depth}] feature-error rms: plain {e_plain:.3e} split {e_split:.3e} " + " ".join(f"{k}: {v:.3e}" for k, v in got.items()))
     assert all(e_split * 0.9 <= v < e_plain for v in got.values())
     assert got["mlp comp"] < got["mlp comp, W_lo term"] < e_plain and got["attn split"] <= got["attn split, comp qkv"] * 1.05 and got["attn split, comp qkv"] < got["comp qkv only"]
+    # the CLS rows redone as split products: the pooled feature is one of them, so most of the MLP's error share goes with 0.5 % of the rows
+    assert got["mlp plain + CLS rows split"] < 0.93 * e_plain
+    m.set_plan([(1, 4)] * depth); e_cls = err(m.encode_image(x))
+    m.set_plan([(1, 0)] * depth); e_attn_only = err(m.encode_image(x))
+    m.set_plan([(1, 2)] * depth); e_comp = err(m.encode_image(x))
+    print(f"[plans, depth {depth}] attention side split + MLP: plain {e_attn_only:.3e}, CLS rows split {e_cls:.3e}, compensated {e_comp:.3e}")
+    assert e_cls < 0.6 * e_attn_only
     # a shorthand rewrites the whole plan; the model object re-applies a custom plan to a fresh handle
-    m.set_plan([(1, 2), (3, 3), (0, 3), (2, 0)])
+    m.set_plan([(1, 2), (3, 3), (0, 4), (2, 0)])
     b = m.encode_image(x)
+    small_b = m.encode_image(x[:3])                                      # graph-replayed small call: the CLS fix-up is captured with it
+    assert torch.equal(m.encode_image(x[:3]), small_b) and (small_b - b[:3]).norm(dim=1).max() < 2e-3
     m._destroy(); m._host_sd = sd; m.to("cuda:0")
-    assert m.get_plan() == [(1, 2), (3, 3), (0, 3), (2, 0)] and torch.equal(m.encode_image(x), b)
+    assert m.get_plan() == [(1, 2), (3, 3), (0, 4), (2, 0)] and torch.equal(m.encode_image(x), b)
     m.set_option("comp_mlp_blocks", 1)
     assert m.get_plan() == prefix_plan(depth, 0, 1) and m.get_option("plan_custom") == 0
     lib = _lib.load()
-    for bad in ((0, 4, 0), (0, 0, 4), (64, 1, 1), (-1, 1, 1)):
+    for bad in ((0, 4, 0), (0, 0, 5), (64, 1, 1), (-1, 1, 1)):
         assert lib.keep_set_block_precision(m._handle, *bad) == _lib.KEEP_EINVAL
     with pytest.raises(ValueError):
         m.set_plan([(0, 7)])

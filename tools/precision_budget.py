@@ -32,7 +32,7 @@ from keep_amd.model import (CALIBRATION_POPULATION, COMP_LADDER, max_sigmas_quan
 from keep_amd.synth import synth_prompts, synth_state_dict                               # noqa: E402
 
 A_PLAIN, A_SPLIT, A_SPLITQ, A_COMPQ = _lib.ATTN_PLAIN, _lib.ATTN_SPLIT, _lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_COMPQKV
-M_PLAIN, M_SPLIT, M_COMP, M_COMPW = _lib.MLP_PLAIN, _lib.MLP_SPLIT, _lib.MLP_COMP, _lib.MLP_COMP_W
+M_PLAIN, M_SPLIT, M_COMP, M_COMPW, M_CLS = _lib.MLP_PLAIN, _lib.MLP_SPLIT, _lib.MLP_COMP, _lib.MLP_COMP_W, _lib.MLP_CLS
 
 
 def main():
@@ -82,7 +82,7 @@ def main():
 
     # ---- variance per (block, site treatment), everything else split -------------------------------------------------------------
     knobs = {"attn_plain": (A_PLAIN, None), "attn_compqkv_plain_rest": (A_COMPQ, None), "attn_split_compqkv": (A_SPLITQ, None),
-             "mlp_plain": (None, M_PLAIN), "mlp_comp": (None, M_COMP), "mlp_comp_w": (None, M_COMPW)}
+             "mlp_plain": (None, M_PLAIN), "mlp_comp": (None, M_COMP), "mlp_comp_w": (None, M_COMPW), "mlp_cls": (None, M_CLS)}
     var = {k: [] for k in knobs}
     for i in range(depth):
         for k, (am, mm) in knobs.items():
@@ -108,7 +108,7 @@ def main():
         return (time.perf_counter() - t0) / args.steps * 1e3
 
     cost_knobs = {"attn_split": (A_SPLIT, None), "attn_split_compqkv": (A_SPLITQ, None), "attn_compqkv": (A_COMPQ, None),
-                  "mlp_comp": (None, M_COMP), "mlp_comp_w": (None, M_COMPW)}
+                  "mlp_comp": (None, M_COMP), "mlp_comp_w": (None, M_COMPW), "mlp_cls": (None, M_CLS)}
     cost = {k: {} for k in cost_knobs}
     base_ms = []
     if not args.skip_cost:
@@ -139,12 +139,14 @@ def main():
     targets = {"location (round 4's rule)": 1e-4 / 5.51, "q=0.90": 1e-4 / max_sigmas_quantile(CALIBRATION_POPULATION, 0.90),
                "q=0.99": 1e-4 / max_sigmas_quantile(CALIBRATION_POPULATION, 0.99)}
     c = {"attn_split": per_block_ms.get("attn_split", 1.0), "attn_split_compqkv": per_block_ms.get("attn_split_compqkv", 0.8),
-         "attn_compqkv": per_block_ms.get("attn_compqkv", 0.2), "mlp_comp": per_block_ms.get("mlp_comp", 0.52), "mlp_comp_w": per_block_ms.get("mlp_comp_w", 0.3)}
+         "attn_compqkv": per_block_ms.get("attn_compqkv", 0.2), "mlp_comp": per_block_ms.get("mlp_comp", 0.52), "mlp_comp_w": per_block_ms.get("mlp_comp_w", 0.3),
+         "mlp_cls": max(per_block_ms.get("mlp_cls", 0.05), 0.01)}
     # what is left of a site's variance under each treatment (measured above, per block)
     left_a = {A_PLAIN: lambda i: var["attn_plain"][i], A_COMPQ: lambda i: var["attn_compqkv_plain_rest"][i], A_SPLITQ: lambda i: var["attn_split_compqkv"][i], A_SPLIT: lambda i: 0.0}
-    left_m = {M_PLAIN: lambda i: var["mlp_plain"][i], M_COMPW: lambda i: var["mlp_comp_w"][i], M_COMP: lambda i: var["mlp_comp"][i], M_SPLIT: lambda i: 0.0}
+    left_m = {M_PLAIN: lambda i: var["mlp_plain"][i], M_COMPW: lambda i: var["mlp_comp_w"][i], M_COMP: lambda i: var["mlp_comp"][i], M_SPLIT: lambda i: 0.0,
+              M_CLS: lambda i: var["mlp_cls"][i]}
     cost_a = {A_PLAIN: 0.0, A_COMPQ: c["attn_compqkv"], A_SPLITQ: c["attn_split_compqkv"], A_SPLIT: c["attn_split"]}
-    cost_m = {M_PLAIN: 0.0, M_COMPW: c["mlp_comp_w"], M_COMP: c["mlp_comp"]}
+    cost_m = {M_PLAIN: 0.0, M_COMPW: c["mlp_comp_w"], M_COMP: c["mlp_comp"], M_CLS: c["mlp_cls"]}
 
     def predict(plan):
         return floor + sum(left_a[a](i) + left_m[mm](i) for i, (a, mm) in enumerate(plan))
@@ -183,11 +185,16 @@ def main():
         print(f"{name:44s} rms {row['probe_rms']:.3e} (predicted {row['predicted_rms']:.3e}) max {mx:.3e}  {ms:7.3f} ms/step  {plan_string(plan)}", flush=True)
         return row
 
-    for full, mlp in COMP_LADDER[2:11]:
+    for full, mlp in COMP_LADDER[2:9]:
         verify(f"prefix {full}/{mlp}", prefix_plan(depth, full, mlp))
-    allows = {"all knobs": {"attn": [A_COMPQ, A_SPLITQ, A_SPLIT], "mlp": [M_COMPW, M_COMP]},
+    verify("all plain", plain_all)
+    verify("every MLP plain + CLS rows split", [(A_PLAIN, M_CLS)] * depth)
+    verify("block 0 attn split+comp qkv; every MLP plain + CLS rows split", [(A_SPLITQ, M_CLS)] + [(A_PLAIN, M_CLS)] * (depth - 1))
+    verify("block 0 attn split+comp qkv, MLP comp; other MLPs plain + CLS rows split", [(A_SPLITQ, M_COMP)] + [(A_PLAIN, M_CLS)] * (depth - 1))
+    allows = {"all knobs": {"attn": [A_COMPQ, A_SPLITQ, A_SPLIT], "mlp": [M_CLS, M_COMPW, M_COMP]},
+              "no CLS-row knob (round-5 mid-way)": {"attn": [A_COMPQ, A_SPLITQ, A_SPLIT], "mlp": [M_COMPW, M_COMP]},
               "attn split + mlp comp (the prefix family's knobs, any block)": {"attn": [A_SPLIT], "mlp": [M_COMP]},
-              "no one-term": {"attn": [A_COMPQ, A_SPLITQ, A_SPLIT], "mlp": [M_COMP]}}
+              "the product's default knobs": {"attn": [A_SPLITQ, A_SPLIT], "mlp": [M_CLS, M_COMP]}}
     for tname, trms in targets.items():
         for aname, allow in allows.items():
             plan, order = greedy(trms ** 2, allow)
@@ -206,9 +213,9 @@ def main():
     with open(os.path.join(args.out, "precision_budget.md"), "w") as f:
         f.write(f"Probe: {out['probe']}.  All-plain rms {total ** 0.5:.3e}; all-split floor {floor ** 0.5:.3e}.  Shares in % of the all-plain variance; "
                 f"'left' = what remains of the site's share under that treatment.  Costs in ms per 256-tile step (plain plan: {base:.2f} ms).\n\n")
-        f.write("| block | attn side plain | left: comp. qkv only | left: split + comp. qkv | MLP plain | left: MLP comp (2 terms) | left: MLP comp (W_lo only) |\n|---|---|---|---|---|---|---|\n")
+        f.write("| block | attn side plain | left: comp. qkv only | left: split + comp. qkv | MLP plain | left: MLP comp (2 terms) | left: MLP comp (W_lo only) | left: MLP plain + CLS rows split |\n|---|---|---|---|---|---|---|---|\n")
         for i in range(depth):
-            f.write(f"| {i} | " + " | ".join(f"{var[k][i] / total * 100:.2f}" for k in ("attn_plain", "attn_compqkv_plain_rest", "attn_split_compqkv", "mlp_plain", "mlp_comp", "mlp_comp_w")) + " |\n")
+            f.write(f"| {i} | " + " | ".join(f"{var[k][i] / total * 100:.2f}" for k in ("attn_plain", "attn_compqkv_plain_rest", "attn_split_compqkv", "mlp_plain", "mlp_comp", "mlp_comp_w", "mlp_cls")) + " |\n")
         f.write("\n| knob | ms per block |\n|---|---|\n")
         for k, v in per_block_ms.items():
             f.write(f"| {k} | {v:.3f} |\n")
