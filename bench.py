@@ -38,7 +38,7 @@ rccl_env()        # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: what RCCL's multi-
 
 from keep_amd import KEEPModel, PROFILE_TAGS, vit_flops_per_tile          # noqa: E402
 from keep_amd.config import KEEPShape                                      # noqa: E402
-from keep_amd.model import plan_string                                    # noqa: E402
+from keep_amd.model import plan_prefix, plan_string                       # noqa: E402
 from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles    # noqa: E402
 
 PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense
@@ -627,9 +627,10 @@ def main():
                        "tiles_per_gpu_per_step": B, "precision": args.precision,
                        "exchange": "RCCL all_gather of [256,768] fp32 embeddings per step" if use_dist else "none",
                        "comp_settings": {"comp_full_blocks": int(model.get_option("comp_full_blocks")), "comp_mlp_blocks": int(model.get_option("comp_mlp_blocks")),
-                                         "plan": plan_string(model.get_plan()), "plan_is_prefix": not bool(model.get_option("plan_custom")),
+                                         "plan": plan_string(model.get_plan()), "plan_is_prefix": plan_prefix(model.get_plan()) is not None,
                                          "label_margin": model.get_option("label_margin"),
-                                         "chosen_by": "KEEPModel.calibrate() at load_state_dict" if model.calibration else "built-in default"},
+                                         "bias_correction": bool(model.get_option("bias_ready") and model.get_option("bias_correction")),
+                                         "chosen_by": "KEEPModel.calibrate() at load_state_dict" if model.calibration else "the plan a handle starts with"},
                        "mfma_frac_end_to_end": round(frac_e2e, 4)},
             "roofline": roofline,
         }

@@ -115,9 +115,11 @@ int keep_bert_layers(keep_handle* h);
 /* ---- options ----------------------------------------------------------------------------------
  *   "precision"       KEEP_PREC_COMP (default) | KEEP_PREC_FP16 | KEEP_PREC_STRICT
  *   "strict_blocks"   run the first n ViT blocks (+ patch embed) / BERT layers in split mode (default 0)
- *   "comp_full_blocks" KEEP_PREC_COMP, prefix shorthand: the first n ViT blocks get KEEP_ATTN_SPLIT, the rest KEEP_ATTN_PLAIN (default 1)
- *   "comp_mlp_blocks"  KEEP_PREC_COMP, prefix shorthand: the first n ViT blocks get KEEP_MLP_COMP, the rest KEEP_MLP_PLAIN (default 8).
- *                     Setting any of the four comp_* shorthands REWRITES the whole per-block plan (keep_set_block_precision below).
+ *   "comp_full_blocks" KEEP_PREC_COMP, prefix shorthand: the first n ViT blocks get KEEP_ATTN_SPLIT, the rest KEEP_ATTN_PLAIN (1 unless set)
+ *   "comp_mlp_blocks"  KEEP_PREC_COMP, prefix shorthand: the first n ViT blocks get KEEP_MLP_COMP, the rest KEEP_MLP_PLAIN (8 unless set).
+ *                     Setting any of the four comp_* shorthands REWRITES the whole per-block plan (keep_set_block_precision below) to that prefix
+ *                     family.  A handle STARTS with another plan: block 0 KEEP_ATTN_SPLIT_COMPQKV + KEEP_MLP_COMP, every other block
+ *                     KEEP_ATTN_PLAIN + KEEP_MLP_CLS -- until KEEPModel.calibrate / keep_set_block_precision replace it.
  *   "plan_custom"      (read only) 1 if keep_set_block_precision changed the plan since the last shorthand
  *   "comp_min_tiles"   sub-batches with fewer tiles use split products instead of compensated ones (default 32)
  *   "comp_qkv"         KEEP_PREC_COMP: 1 = the qkv GEMM of the split-attention blocks as a compensated product instead of a split one

@@ -95,8 +95,7 @@ struct keep_handle {
     KeepTune tune;               // kernel selection (travels in the launch parameter blocks; nothing is process-wide)
     int precision = KEEP_PREC_COMP;
     int strict_blocks = 0;       // first n blocks / layers as full hi/lo split products (any mode)
-    // Defaults from measurements on the 262 144 cosines of BASELINE config 3 (profiles/r02_precision_modes.txt): (1, 8) gives
-    // max |dcos| 7.6-7.9e-5 (21-27 % head-room on fresh tiles / other weights), (2, 12) 7.1e-5 at -8 % throughput, (1, 6) 8.5e-5.
+    // The prefix shorthands (state of the last keep_set_option; they only take effect once one of them is set -- see plan_default below)
     int comp_full_blocks = 1;    // KEEP_PREC_COMP: first n ViT blocks run qkv / attention / proj as split products as well
     int comp_mlp_blocks = 8;     // KEEP_PREC_COMP: first n ViT blocks run fc1 / fc2 as compensated (fp16 + MX-fp4) products
     int fused_screening = 1;     // keep_prompt_scores: 1 fused compensated GEMM (default) | 2 fused 3-pass split GEMM | 0 logits through HBM (any C)
@@ -122,7 +121,17 @@ struct keep_handle {
         }
         plan_custom = false;
     }
-    keep_handle() { plan_from_prefix(); }
+    // The plan a handle starts with (no calibration has seen the weights yet): block 0's attention side as split products with a compensated qkv
+    // and its MLP compensated -- the first block's rounding errors, in EVERY row, are amplified by all the attention layers that follow: 45-48 % of the
+    // all-fp16 error variance on the synthetic checkpoints --, every other block plain with the CLS rows' MLP redone as split products (the pooled
+    // feature is a CLS row).  profiles/r05_precision_budget.md: cosine rms 8.5e-6 on the bench weights, a quarter of what the 1e-4 tolerance allows a
+    // 100 000-tile slide, 3 % slower than what KEEPModel.calibrate picks for them.
+    void plan_default() {
+        for (int i = 0; i < MAX_BLOCKS; ++i) { attn_mode[i] = KEEP_ATTN_PLAIN; mlp_mode[i] = KEEP_MLP_CLS; }
+        attn_mode[0] = KEEP_ATTN_SPLIT_COMPQKV; mlp_mode[0] = KEEP_MLP_COMP;
+        plan_custom = false;
+    }
+    keep_handle() { plan_default(); }
     // keep_classify: tiles whose top-2 cosine margin is below this are re-encoded in KEEP_PREC_STRICT before their label is taken.
     // Default = 2 x the north-star tolerance (both cosines of a pair can move by 1e-4 in opposite directions) + 25 %.
     float label_margin = 2.5e-4f;

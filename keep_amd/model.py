@@ -42,7 +42,7 @@ CONFIDENCE = 0.99
 PROBE_RMS_MARGIN = 1.02
 # Milliseconds a knob adds to a 256-tile encode step on an MI355X (two lanes; tools/precision_budget.py measures them, profiles/r05_precision_budget.md):
 # what the greedy of budget="measured" divides a knob's variance share by.  Only the RATIOS matter.
-KNOB_COST_MS = {"attn_split": 0.93, "attn_split_compqkv": 0.57, "attn_compqkv": 0.24, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.05}
+KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.10}
 # Share of a site's rounding variance that survives a treatment when it is not measured on the loaded weights (same tool, bench weights): both
 # MX-fp4 correction terms remove ~96 % of an MLP's share, the W_lo term alone 40-55 %; a compensated qkv inside a split attention side leaves 1-2 %
 MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_CLS: 0.1, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}
@@ -52,7 +52,7 @@ ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_SPLIT_C
 # percent of variance against 0.45 for MLP blocks -- neither ever wins a greedy step, so they are off by default (``knobs=`` switches them on).
 # KEEP_MLP_CLS (every row plain, the CLS row of every tile again as split products) is the cheap one: the feature is pooled from the CLS rows, whose
 # own rounding errors reach it directly while the other 196 rows' only arrive through attention averages -- what it leaves of a block's MLP share is
-# measured per block (4-6 % outside the first block on the bench weights, 25-30 % in block 0).
+# measured per block (0.5-2 % on the bench weights).
 DEFAULT_KNOBS = {"attn": (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_CLS, _lib.MLP_COMP)}
 
 Plan = List[Tuple[int, int]]
@@ -166,7 +166,7 @@ class KEEPModel:
         self._flag_pool = []              # pinned buffers are recycled only after their copy has landed
         # load_state_dict on a GPU ends with calibrate(): the cheapest 'comp' setting whose worst cosine error on a seeded probe batch
         # (against the engine's own split-product arithmetic) predicts a worst error inside the tolerance over CALIBRATION_POPULATION cosines.  KEEP_CALIBRATE=0 / auto_calibrate=False: keep the
-        # built-in default (1, 8), which was chosen on ONE synthetic weight family.
+        # plan a handle starts with (block 0 treated in full, the CLS rows' MLP redone as split products everywhere else), which no measurement on THESE weights backs.
         self.auto_calibrate = os.environ.get("KEEP_CALIBRATE", "1") != "0"
         # "measured": one split-product encode of a 64-tile probe per block and half ranks the knobs for THESE weights, then a greedy plan is verified
         # (about 2 s at load for ViT-L); "ladder": the prefix family COMP_LADDER only (under 1 s, up to 12 % slower plans -- profiles/r05_precision_budget.md)

@@ -527,10 +527,12 @@ def test_compensated_mode_takes_the_fp4_path_on_bench_sized_lanes(small, text_ba
     with torch.no_grad():
         ref = O.encode_image(small, x) @ text_bank.t()
     errs = {}
-    for name, precision, opts in (("fp16", "fp16", {}), ("comp", "comp", {}), ("comp, attention side plain", "comp", {"comp_full_blocks": 0}),
-                                  ("comp, one lane", "comp", {"streams": 1}), ("comp, qkv of block 0 compensated instead of split", "comp", {"comp_qkv": 1})):
+    p18 = {"comp_full_blocks": 1, "comp_mlp_blocks": 8}        # the prefix plan 1 / 8: every MLP GEMM of this depth-2 model on the fp16 + MX-fp4 kernels
+    for name, precision, opts in (("fp16", "fp16", {}), ("comp", "comp", p18), ("comp, attention side plain", "comp", {**p18, "comp_full_blocks": 0}),
+                                  ("comp, one lane", "comp", {**p18, "streams": 1}),
+                                  ("comp, qkv of block 0 compensated instead of split", "comp", {**p18, "comp_qkv": 1}), ("comp, the handle's initial plan", "comp", {})):
         m = KEEPModel(precision=precision, towers=towers_of(small))
-        m.auto_calibrate = False                  # the built-in setting (1 / 8): this test is about the fp4 path, not about what calibrate() picks
+        m.auto_calibrate = False                  # explicit plans: this test is about the fp4 path, not about what calibrate() picks
         m.load_state_dict(small, strict=True)
         m.to("cuda:0")
         for k, v in opts.items():
@@ -539,6 +541,7 @@ def test_compensated_mode_takes_the_fp4_path_on_bench_sized_lanes(small, text_ba
         errs[name] = (d.max().item(), d.pow(2).mean().sqrt().item())
         print(f"[64 tiles d2 {name}] max|dcos|={errs[name][0]:.3e} rms={errs[name][1]:.3e}")
     assert errs["comp"][0] < COS_TOL and errs["comp, one lane"][0] < COS_TOL and errs["comp, qkv of block 0 compensated instead of split"][0] < COS_TOL
+    assert errs["comp, the handle's initial plan"][0] < COS_TOL and errs["comp, the handle's initial plan"][1] < 0.5 * errs["fp16"][1]
     assert errs["comp"][1] < 0.5 * errs["fp16"][1]
     assert errs["comp, attention side plain"][1] < 0.8 * errs["fp16"][1]
 
@@ -752,7 +755,7 @@ def test_weight_families_calibrated_default_mode_within_tolerance(golden_dir, fa
     m2.to("cuda:0")
     assert m2.calibration is None
     d2 = (m2.encode_image(x.cuda()).cpu() @ txt.cpu().t() - ref).abs()
-    print(f"[family {family}] built-in 1/8 without calibration: max|dcos| {d2.max():.3e}")
+    print(f"[family {family}] the handle's initial plan without calibration: max|dcos| {d2.max():.3e}")
 
 
 @pytest.mark.parametrize("budget", ["ladder", "measured"])
@@ -821,7 +824,8 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     m.auto_calibrate = False
     m.load_state_dict(sd, strict=True)
     m.to("cuda:0")
-    assert m.get_plan() == prefix_plan(depth, 1, 8)[:depth] and m.get_option("plan_custom") == 0          # the built-in 1 / 8, clamped to the depth
+    assert m.get_plan() == [(_lib.ATTN_SPLIT_COMPQKV, _lib.MLP_COMP)] + [(_lib.ATTN_PLAIN, _lib.MLP_CLS)] * (depth - 1)      # what a handle starts with
+    assert m.get_option("plan_custom") == 0
     m.set_option("comp_full_blocks", 1); m.set_option("comp_mlp_blocks", 2)
     a = m.encode_image(x)
     m.set_plan(prefix_plan(depth, 1, 2))
