@@ -425,7 +425,10 @@ class KEEPModel:
 
             rms x PROBE_RMS_MARGIN x max_sigmas_quantile(population, confidence) x tail <= tolerance
 
-        ``tail`` >= 1 only when the probe's own maximum is larger than a Gaussian sample of its size allows at 99 % (heavier tails than the model
+        ``rms`` = the larger of (a) the rms cosine error against the probe's prompt bank and (b) the ISOTROPIC figure |feature error| / sqrt(D) -- what
+        the rms would be against prompts in random directions.  Error vectors are not isotropic, so a bank can see 5-10 % less (or more) than another
+        (measured: 1.48e-5 against the probe bank, 1.60e-5 against two other banks and isotropically, same plan); holding the plan to both keeps the
+        choice from leaning on one bank's luck.  ``tail`` >= 1 only when the probe's own maximum is larger than a Gaussian sample of its size allows at 99 % (heavier tails than the model
         assumes).  ``model.calibration`` reports the prediction and the ``exceedance_probability`` of the chosen plan.  Candidates: ``budget="ladder"``
         walks ``COMP_LADDER`` (prefix plans); ``budget="measured"`` first measures, on these weights, the variance share of every block's attention
         side and MLP (one split-product encode per block and half with that one site downgraded), then builds the plan greedily by share / cost
@@ -471,19 +474,23 @@ class KEEPModel:
         done = False
 
         def probe(plan: Plan):
-            """Encode the probe under `plan`; (max, rms, predicted population maximum at the confidence level)."""
+            """Encode the probe under `plan`; (max, rms, predicted population maximum at the confidence level, tail factor, bank rms, isotropic rms)."""
             self.set_plan(plan)
-            d = self.similarity(self.encode_image(tiles), bank).sub_(ref).abs_()
-            err, rms = float(d.max()), float(d.pow(2).mean().sqrt())
-            tail = max(1.0, (err / rms) / z_probe99) if rms > 0 else 1.0
-            return err, rms, rms * PROBE_RMS_MARGIN * z_pop * tail, tail
+            f = self.encode_image(tiles)
+            d = self.similarity(f, bank).sub_(ref).abs_()
+            err, rms_bank = float(d.max()), float(d.pow(2).mean().sqrt())
+            rms_iso = float((f - ref_f).pow(2).sum(dim=1).mean().div(f.shape[1]).sqrt())
+            rms = max(rms_bank, rms_iso)
+            tail = max(1.0, (err / rms_bank) / z_probe99) if rms_bank > 0 else 1.0
+            return err, rms, rms * PROBE_RMS_MARGIN * z_pop * tail, tail, rms_bank, rms_iso
 
         def consider(plan: Plan) -> bool:
             nonlocal chosen, chosen_stats
-            err, rms, pred, tail = probe(plan)
+            err, rms, pred, tail, rms_bank, rms_iso = probe(plan)
             pre = plan_prefix(plan)
             tried.append({"comp_full_blocks": pre[0] if pre else None, "comp_mlp_blocks": pre[1] if pre else None, "plan": plan_string(plan),
-                          "max_abs_dcos": float(f"{err:.3e}"), "rms_dcos": float(f"{rms:.3e}"), "predicted_max_abs_dcos": float(f"{pred:.3e}")})
+                          "max_abs_dcos": float(f"{err:.3e}"), "rms_dcos": float(f"{rms:.3e}"), "rms_dcos_vs_bank": float(f"{rms_bank:.3e}"),
+                          "rms_dcos_isotropic": float(f"{rms_iso:.3e}"), "predicted_max_abs_dcos": float(f"{pred:.3e}")})
             if pred <= tolerance:                 # (NaN compares False: falls through to the next candidate)
                 chosen, chosen_stats = plan, (err, rms, pred, tail)
                 return True
@@ -491,7 +498,8 @@ class KEEPModel:
 
         try:
             self.set_precision("strict", strict_blocks)
-            ref = self.similarity(self.encode_image(tiles), bank)           # cosines on the engine's exact-fp32 similarity kernel
+            ref_f = self.encode_image(tiles)
+            ref = self.similarity(ref_f, bank)                              # cosines on the engine's exact-fp32 similarity kernel
             self.set_precision("comp", strict_blocks)
             if not bool(torch.isfinite(ref).all()):
                 self._raise_flags(2)
@@ -501,7 +509,7 @@ class KEEPModel:
                         break
             else:
                 n_sh = min(tiles.shape[0], 64)             # the shares only rank the knobs: a quarter of the probe is enough (and 4 x faster)
-                shares = self._measure_shares(tiles[:n_sh], bank, ref[:n_sh], depth)
+                shares = self._measure_shares(tiles[:n_sh], ref_f[:n_sh], depth)
                 walk = self._greedy_walk(shares, depth, knobs or DEFAULT_KNOBS)
                 # the sum of measured shares over-predicts the rms of a plan by 3-11 % (variances of neighbouring sites do not quite add): start the
                 # verification a little before the predicted crossing and walk up one knob at a time until a plan verifies
@@ -545,21 +553,25 @@ class KEEPModel:
             self.calibration["variance_shares"] = shares
         return self.calibration
 
-    def _measure_shares(self, tiles, bank, ref, depth: int) -> dict:
+    def _measure_shares(self, tiles, ref_f, depth: int) -> dict:
         """Cosine-error variance each block's attention side / MLP contributes when it alone runs single fp16 passes and everything else split
         products (so the figure is that site's own rounding error, not the re-drawn rounding of everything downstream), plus what is left of a
-        site's share under the cheaper treatments, measured on block 0 (and a middle block for the MLP forms)."""
+        site's share under the cheaper treatments.  Variances are the isotropic ones -- |feature error|^2 / D, the mean squared cosine error over
+        random prompt directions -- which ranks the knobs independently of any prompt bank."""
         split = [(_lib.ATTN_SPLIT, _lib.MLP_SPLIT)] * depth
+
+        def iso_var():
+            f = self.encode_image(tiles)
+            return float((f - ref_f).pow(2).sum(dim=1).mean().div(f.shape[1]))
 
         def var_of(i, mode):
             p = list(split)
             p[i] = mode
             self.set_plan(p)
-            d = self.similarity(self.encode_image(tiles), bank).sub_(ref)
-            return float(d.pow(2).mean())
+            return iso_var()
 
         self.set_plan(split)
-        floor = float(self.similarity(self.encode_image(tiles), bank).sub_(ref).pow(2).mean())
+        floor = iso_var()
         attn = [max(var_of(i, (_lib.ATTN_PLAIN, _lib.MLP_SPLIT)) - floor, 0.0) for i in range(depth)]
         mlp = [max(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_PLAIN)) - floor, 0.0) for i in range(depth)]
         res_m, res_a = dict(MLP_RESIDUAL), dict(ATTN_RESIDUAL)
