@@ -388,6 +388,8 @@ def main():
     ap.add_argument("--c4-tiles", type=int, default=100_000)
     ap.add_argument("--c4-seeds", type=int, default=len(C4_SEEDS), help="number of 100 000-tile synthetic slides of the config-4 leg (about 50 s each)")
     ap.add_argument("--budget", default=None, choices=["ladder", "measured"], help="re-run KEEPModel.calibrate with this budget after loading")
+    ap.add_argument("--plan", default=None, help="run this per-block plan instead of the calibrated one: the 'attn:<digits> mlp:<digits>' string a bench line "
+                                                 "reports (profiling runs: KEEP_CALIBRATE=0 keeps the calibration's kernels out of the trace)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -419,6 +421,9 @@ def main():
     model.to(dev).eval()
     if args.budget is not None and args.precision == "comp":
         model.calibrate(budget=args.budget)
+    if args.plan is not None:
+        a_digits, m_digits = (part.split(":")[1] for part in args.plan.split())
+        model.set_plan([(int(a), int(m)) for a, m in zip(a_digits, m_digits)])
     for kv in args.opt:
         k, v = kv.split("=")
         model.set_option(k, float(v))

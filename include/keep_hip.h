@@ -135,6 +135,11 @@ int keep_bert_layers(keep_handle* h);
  *                     back onto the caller's stream with events (no host synchronisation)
  *   "cls_tail"        1 (default): in the last ViT block run proj / MLP for the CLS rows only (exact: the
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
+ *   "cls_qkv"         1: with cls_tail, the last block's qkv GEMM computes K | V for every token and Q for the CLS rows only (exact).  Default 0: measured level
+ *                     end to end (-0.09 ms of qkv, +0.02 ms of small launches per 256-tile step)
+ *   "proj_impl"       2128: the plain proj GEMMs on the 256x128 / 4-wave / two-workgroups-per-CU kernel (one workgroup's residual epilogue under the other's K
+ *                     loop).  Default 0: -8.5 % on the proj launches alone, level end to end with two lanes (profiles/r05_ab_proj_and_cls_qkv.txt)
+ *   "bias_correction" 1 (default): plain launches use the mean-input-compensated biases once keep_calibrate_bias has run | 0: the checkpoint's biases
  *   "gemm_impl"       0 auto | 128 | 256: LDS-DMA tile width override.  Like every option it belongs to the handle.
  *   "graphs"          1 (default): launch-bound calls -- keep_encode_image of at most 1024 token rows (5 tiles), keep_encode_text of at most
  *                     4096 token rows (e.g. 64 prompts x 64 tokens) -- are captured once per shape and replayed as one hipGraph launch (~100

@@ -152,7 +152,9 @@ struct keep_handle {
         for (auto& c : cal) for (int k = 0; k < 4; ++k) { if (c.sum[k]) (void)hipFree(c.sum[k]); if (c.bias[k]) (void)hipFree(c.bias[k]); }
         cal.clear(); bias_ready = false;
     }
-    int cls_qkv = 1;             // last ViT block (with cls_tail): the q part of the qkv GEMM for the CLS rows only (exact; 0 = all rows)
+    int cls_qkv = 0;             // 1: last ViT block (with cls_tail): the q part of the qkv GEMM for the CLS rows only (exact).  Measured (round 5, tools/ab_options.py):
+                                 // vit.qkv -0.09 ms per step on one stream, +0.02 ms of small launches, 6041 vs 6044 tiles/s end to end with two lanes: below the
+                                 // 0.3 % it would have to return -- off by default
     int proj_impl = 0;           // 2128: the plain proj GEMMs of the image tower on the 256x128 / two-workgroups-per-CU kernel (GemmParams.impl_hint); 0: the persistent 256x256 kernel
     // hipGraph replay of launch-bound calls (one prompt / one tile: ~100 dependent kernels of a few us each)
     struct GraphSlot { hipGraphExec_t exec; unsigned long long epoch; char* arena; };

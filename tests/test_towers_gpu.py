@@ -425,13 +425,14 @@ def test_cls_only_tail_is_exact(small, no_splitk):
 
 def test_last_block_query_for_the_cls_rows_only(small):
     """Lanes of >= 32 tiles: the last block's qkv GEMM computes K | V for every token and Q for the CLS rows alone (a [B, D] x W_q^T product on the
-    small-M kernel, engine option cls_qkv, default on) -- every other token's query is never read.  Same features as with all 3 D columns computed,
+    small-M kernel, engine option cls_qkv) -- every other token's query is never read.  Same features as with all 3 D columns computed,
     to the fp16 rounding of the CLS query (the two kernels sum K in different orders); both inside the mode's tolerance of the oracle."""
     x = synth_tiles(70, seed=17)                                   # two lanes of 35 tiles
     with torch.no_grad():
         ref = O.encode_image(small, x)
     for precision in ("fp16", "comp"):
         m = make_model(small, precision)
+        m.set_option("cls_qkv", 1)                                 # (off by default: measured level end to end)
         m.profile_enable("vit.tail")
         m.profile_reset()
         fast = m.encode_image(x.cuda())

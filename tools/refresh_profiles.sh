@@ -6,29 +6,29 @@
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof; rm -rf "$OUT"; mkdir -p "$OUT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"
-get() { python -c "import json;print(json.load(open('$OUT/bench.json'))['config']['comp_settings']['$1'])"; }
-SET="--opt comp_full_blocks=$(get comp_full_blocks) --opt comp_mlp_blocks=$(get comp_mlp_blocks)"
+PLAN=$(python -c "import json;print(json.load(open('$OUT/bench.json'))['config']['comp_settings']['plan'])")
+SET=(--plan "$PLAN")
 LEAN="--no-cpu-baseline --no-configs --no-sustained"
 export KEEP_CALIBRATE=0
 cd /tmp && export TMPDIR=/tmp
 # 1. per-kernel time summary of the bench command (two internal lanes, as the bench runs)
-rocprofv3 --kernel-trace --stats -d /tmp/kt --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 $LEAN $SET \
+rocprofv3 --kernel-trace --stats -d /tmp/kt --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 $LEAN "${SET[@]}" \
     > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/kt.log"
 cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 # 2. the same on ONE internal stream: per-kernel durations with nothing else on the GPU (what bench.py's roofline.single_stream figures are made of)
-rocprofv3 --kernel-trace --stats -d /tmp/kt1 --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 $LEAN --no-breakdown --opt streams=1 $SET \
+rocprofv3 --kernel-trace --stats -d /tmp/kt1 --output-format csv -- python "$REPO/bench.py" --steps 10 --warmup 3 $LEAN --no-breakdown --opt streams=1 "${SET[@]}" \
     > "$OUT/bench_single_stream_under_rocprofv3.json" 2> "$OUT/kt1.log"
 cp "$(find /tmp/kt1 -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_single_stream.csv"
 # 3. counters: their own passes, kernel-trace only (FETCH_SIZE and WRITE_SIZE do not share a pass); one internal stream, so a launch is 256 tiles --
 #    the same launch bench.py's roofline.flops_per_launch / avg_launch_ms describe
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 $LEAN --no-breakdown --opt streams=1 $SET \
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c --output-format csv -- python "$REPO/bench.py" --steps 3 --warmup 1 $LEAN --no-breakdown --opt streams=1 "${SET[@]}" \
       > /dev/null 2> "$OUT/pmc_$c.log"
 done
 # 4. matrix-pipe utilisation and clock, two lanes and one stream (clean per-kernel attribution) -> the per-kernel table
 for v in "" "1"; do
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_MFMA$v --output-format csv -- \
-      python "$REPO/bench.py" --steps 3 --warmup 1 $LEAN --no-breakdown $SET ${v:+--opt streams=1} > /dev/null 2> "$OUT/pmc_MFMA$v.log"
+      python "$REPO/bench.py" --steps 3 --warmup 1 $LEAN --no-breakdown "${SET[@]}" ${v:+--opt streams=1} > /dev/null 2> "$OUT/pmc_MFMA$v.log"
 done
 cd "$REPO"
 python tools/pmc_summary.py "$(find /tmp/pmc_MFMA -name '*counter_collection.csv' | head -1)" > "$OUT/mfma_busy.txt" 2>&1
