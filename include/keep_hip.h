@@ -137,8 +137,9 @@ int keep_bert_layers(keep_handle* h);
  *                     pooled output reads nothing else); 0: evaluate every token as the reference does
  *   "cls_qkv"         1: with cls_tail, the last block's qkv GEMM computes K | V for every token and Q for the CLS rows only (exact).  Default 0: measured level
  *                     end to end (-0.09 ms of qkv, +0.02 ms of small launches per 256-tile step)
- *   "proj_impl"       2128: the plain proj GEMMs on the 256x128 / 4-wave / two-workgroups-per-CU kernel (one workgroup's residual epilogue under the other's K
- *                     loop).  Default 0: -8.5 % on the proj launches alone, level end to end with two lanes (profiles/r05_ab_proj_and_cls_qkv.txt)
+ *   "proj_impl"       2128 (default): the plain proj GEMMs on the 256x128 / 4-wave / two-workgroups-per-CU kernel (one workgroup's residual epilogue under the
+ *                     other's K loop): -8.5 % on the proj launches, +0.57 % end to end (profiles/r05_ab_two_workgroups_per_cu.txt) | 0: the persistent 256x256 kernel.
+ *                     Bit-identical results.  "impl2128_mask" (experiments): the same kernel for qkv (1) / fc1 (4) / fc2 (8): measured -1.6 ... -4.3 %
  *   "bias_correction" 1 (default): plain launches use the mean-input-compensated biases once keep_calibrate_bias has run | 0: the checkpoint's biases
  *   "gemm_impl"       0 auto | 128 | 256: LDS-DMA tile width override.  Like every option it belongs to the handle.
  *   "graphs"          1 (default): launch-bound calls -- keep_encode_image of at most 1024 token rows (5 tiles), keep_encode_text of at most

@@ -155,7 +155,12 @@ struct keep_handle {
     int cls_qkv = 0;             // 1: last ViT block (with cls_tail): the q part of the qkv GEMM for the CLS rows only (exact).  Measured (round 5, tools/ab_options.py):
                                  // vit.qkv -0.09 ms per step on one stream, +0.02 ms of small launches, 6041 vs 6044 tiles/s end to end with two lanes: below the
                                  // 0.3 % it would have to return -- off by default
-    int proj_impl = 0;           // 2128: the plain proj GEMMs of the image tower on the 256x128 / two-workgroups-per-CU kernel (GemmParams.impl_hint); 0: the persistent 256x256 kernel
+    // 2128 (default): the plain proj GEMMs of the image tower on the 256x128 / 4-wave / two-workgroups-per-CU kernel (GemmParams.impl_hint) -- proj is the one GEMM whose
+    // tile is 40 % fp32 residual read-modify-write epilogue, and with two workgroups on a CU one's epilogue runs under the other's K loop: -8.5 % on the proj launches,
+    // +0.57 % end to end in a six-round rotated A/B on the round-5 plan (profiles/r05_ab_two_workgroups_per_cu.txt; qkv / fc1 / fc2 on the same kernel lose 1.6-4.3 %:
+    // 1.5 x the operand bytes per FLOP).  0: the persistent 256x256 kernel.  Bit-identical results either way (same K order per output).
+    int proj_impl = 2128;
+    int impl2128_mask = 0;       // experiments: the same kernel for the plain qkv (1) / fc1 (4) / fc2 (8) launches (2 = proj, same as proj_impl)
     // hipGraph replay of launch-bound calls (one prompt / one tile: ~100 dependent kernels of a few us each)
     struct GraphSlot { hipGraphExec_t exec; unsigned long long epoch; char* arena; };
     std::map<std::string, GraphSlot> graphs;
@@ -517,6 +522,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         Scope sc(h, tag, s);
         capture(0, ws.xn_hi, M, D);
         GemmParams p = gemm_params(h, ws.xn_hi, ws.xn_lo, b.qkv, M, sp && !qkv_q, site_bias(0, b.qkv_b, !sp && !qkv_q));
+        if (!sp && !qkv_q && (h->impl2128_mask & 1)) p.impl_hint = 2128;
         if (kv_only) {          // weight rows D .. 3D-1 (n-tiles D/256 ..), written into columns D .. 3D-1 of the token-major qkv buffer
             p.N = 2 * D; p.w_hi += (int64_t)(D / 256) * (D / 32) * 8192; p.bias += D; p.out_ld = 3 * D; p.out_col0 = D;
         }
@@ -567,7 +573,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         Scope sc(h, tag, s);
         capture(1, att_hi, Mr, D);
         GemmParams p = gemm_params(h, att_hi, att_lo, b.proj, Mr, sp, site_bias(1, b.proj_b, !sp));
-        p.ls = b.ls1; p.resid = resid; p.impl_hint = h->proj_impl;
+        p.ls = b.ls1; p.resid = resid; p.impl_hint = (h->impl2128_mask & 2) ? 2128 : h->proj_impl;
         if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
         did = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
         if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
@@ -587,6 +593,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         capture(2, xn_hi, Mr, D);
         GemmParams p = gemm_params(h, xn_hi, xn_lo, b.fc1, Mr, mlp_lo, site_bias(2, b.fc1_b, mlp_plain));
         p.out_hi = mlp_hi; p.out_lo = mlp_lo ? mlp_lo_p : nullptr; p.out_kt = h->vit_F / 32;
+        if (mlp_plain && (h->impl2128_mask & 4)) p.impl_hint = 2128;
         if (mlp_q) {
             p.comp = mlp_comp; p.a_q = ws.xn_q; p.a_sc = ws.xn_sc; p.w_q = b.fc1->q; p.w_sc = b.fc1->sc;
             p.out_q = ws.mlp_q; p.out_sc = ws.mlp_sc;
@@ -600,6 +607,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         capture(3, mlp_hi, Mr, h->vit_F);
         GemmParams p = gemm_params(h, mlp_hi, mlp_lo_p, b.fc2, Mr, mlp_lo, site_bias(3, b.fc2_b, mlp_plain));
         p.ls = b.ls2; p.resid = resid;
+        if (mlp_plain && (h->impl2128_mask & 8)) p.impl_hint = 2128;
         if (mlp_q) { p.comp = mlp_comp; p.a_q = ws.mlp_q; p.a_sc = ws.mlp_sc; p.w_q = b.fc2->q; p.w_sc = b.fc2->sc; }
         if (i + 1 < h->vit_depth && !cls_only && !mlp_cls) {        // next block's LayerNorm-1 reads exactly the rows written here (not when CLS rows are still to be replaced)
             const VitBlock& nb = h->vblocks[i + 1];
@@ -1262,6 +1270,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
     else if (n == "bias_correction") { h->bias_correction = v ? 1 : 0; }
+    else if (n == "impl2128_mask") { if (v < 0 || v > 15) return h->fail(KEEP_EINVAL, "impl2128_mask must be 0..15"); h->impl2128_mask = v; }
     else if (n == "proj_impl") { if (v != 0 && v != 2128) return h->fail(KEEP_EINVAL, "proj_impl must be 0 or 2128"); h->proj_impl = v; }
     else if (n == "streams") { if (v < 1 || v > 4) return h->fail(KEEP_EINVAL, "streams must be 1..4"); h->n_streams = v; }
     else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
@@ -1318,6 +1327,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "lane0_permille") return h->lane0_permille;
     if (n == "cls_tail") return h->cls_tail;
     if (n == "proj_impl") return h->proj_impl;
+    if (n == "impl2128_mask") return h->impl2128_mask;
     if (n == "cls_qkv") return h->cls_qkv;
     if (n == "bias_correction") return h->bias_correction;
     if (n == "bias_ready") return h->bias_ready ? 1 : 0;

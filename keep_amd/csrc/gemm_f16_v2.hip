@@ -778,8 +778,11 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
         return 1;
     }
     if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, 0>(p, s);
-    if (p.impl_hint == 2128 && epi == EPI_RESID_LS && p.nseg == 1 && p.N % 128 == 0 && (p.N / 128) * ((p.M + V2_BM - 1) / V2_BM) > 2 * keep_num_cus())
-        return launch_v2_one<128, 2, 2, 3, EPI_RESID_LS, 0>(p, s);
+    if (p.impl_hint == 2128 && p.nseg == 1 && !p.out_lo && !p.out_q && p.N % 128 == 0 && (p.N / 128) * ((p.M + V2_BM - 1) / V2_BM) > 2 * keep_num_cus()) {
+        if (epi == EPI_RESID_LS) return launch_v2_one<128, 2, 2, 3, EPI_RESID_LS, 0>(p, s);
+        if (epi == EPI_F16) return launch_v2_one<128, 2, 2, 3, EPI_F16, 0>(p, s);
+        if (epi == EPI_GELU_F16) return launch_v2_one<128, 2, 2, 3, EPI_GELU_F16, 0>(p, s);
+    }
     if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
         (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > keep_num_cus()) {
         // (a device that does not grant all 160 KiB of LDS to one workgroup falls through to the one-tile-per-workgroup launch)

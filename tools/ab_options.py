@@ -57,7 +57,8 @@ def main():
         apply(arm)
     feats, rates = {}, {a: [] for a in arms}
     for r in range(args.rounds):
-        for arm in arms:
+        for arm in (arms[r % len(arms):] + arms[:r % len(arms)]):          # rotate the order from round to round: a thermal drift within a round cancels
+
             apply(arm)
             for _ in range(3):
                 f = m.encode_image(tiles)
