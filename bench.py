@@ -43,11 +43,11 @@ from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles    # noq
 
 PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense
 PEAK_HBM_GBS = 8000.0
-# The kernel that takes the largest share of a step: gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,false,true> -- the persistent 256x256 GEMM with the
-# LayerScale + fp32 residual read-modify-write epilogue, launched for proj ([B*197,1024] x [1024,1024]) and fc2 ([B*197,4096] x [4096,1024]) of every
-# block that runs single fp16 passes (the largest share of the step: profiles/r05_per_kernel_table.md).  The engine times those launches under these two tags.
-DOMINANT_TAGS = ("vit.proj", "vit.fc2")
-DOMINANT_KERNEL = "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,false,true> (persistent; vit.proj + vit.fc2 launches of the plain blocks)"
+# The kernel that takes the largest share of a step: gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,0,true> -- the persistent 256x256 GEMM with the
+# LayerScale + fp32 residual read-modify-write epilogue, launched for fc2 ([B*197,4096] x [4096,1024]) of every block that runs it as a single fp16
+# pass (27 % of the step: profiles/r05_per_kernel_table.md; proj has its own kernel since round 5).  The engine times those launches under this tag.
+DOMINANT_TAGS = ("vit.fc2",)
+DOMINANT_KERNEL = "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,0,true> (persistent; the vit.fc2 launches)"
 BERT_FLOPS_PER_PROMPT_256 = 45_903_642_624
 DTYPE_NAME = {"fp16": "fp16", "comp": "fp16+mxfp4", "strict": "fp16x3"}
 
@@ -588,13 +588,14 @@ def main():
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    tj = json.load(open(tpath)).get("vit.proj+fc2", {})
+                    tjs = json.load(open(tpath))
+                    tj = tjs.get("vit.fc2", tjs.get("vit.proj+fc2", {}))
                     traffic = tj.get("bytes_per_launch")
                     traffic_tiles = tj.get("tiles_per_launch", 128)      # the PMC passes run the two-lane bench: 128-tile launches
                     sha_path = os.path.join(ROOT, "profiles", f"{rnd}_lib_sha16.txt")
                     sha = open(sha_path).read().strip() if os.path.exists(sha_path) else "unrecorded"
-                    traffic_src = (f"profiles/{rnd}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this kernel in the two-lane run "
-                                   f"(128-tile launches, proj and fc2 mixed; algorithmic: {tj.get('algorithmic_bytes_per_launch')}), measured on library build {sha}; "
+                    traffic_src = (f"profiles/{rnd}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of this kernel "
+                                   f"({traffic_tiles}-tile launches; algorithmic: {tj.get('algorithmic_bytes_per_launch')}), measured on library build {sha}; "
                                    f"this run's library is {lib_sha16()}")
                     break
                 except (OSError, ValueError):
@@ -604,13 +605,13 @@ def main():
         roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", **rate(dom_ms, dom_n, dom_fl),
                     "traffic": traffic, "traffic_tiles_per_launch": traffic_tiles, "flops_tiles_per_launch": B, "traffic_source": traffic_src,
                     "timing": "single_stream_pass: HIP events around every launch of this kernel, on the stream it is launched on, 3 encode calls of 256 tiles with one "
-                              "internal stream (nothing else on the GPU): a kernel figure, comparable with profiles/r04_rocprofv3_kernel_stats_single_stream.csv",
+                              "internal stream (nothing else on the GPU): a kernel figure, comparable with profiles/r05_rocprofv3_kernel_stats_single_stream.csv",
                     "share_of_single_stream_step": round(dom_ms / max(sum(v[0] for v in single.values()), 1e-9), 4) if single else None,
                     "by_operator": {t: rate(*single[t]) for t in DOMINANT_TAGS if t in single},
                     "in_timed_region_two_lane": {**rate(*(sum(in_region[t][i] for t in DOMINANT_TAGS) for i in range(3))),
                                                  "note": "the same kernel's launches INSIDE the timed region, where two 128-tile lanes share the GPU: a launch's "
                                                          "duration includes the time it spends beside the other lane's kernels -- not a kernel figure"},
-                    "other_kernels_single_stream": {t: rate(*single[t]) for t in ("vit.qkv", "vit.fc1", "vit.fc1.x", "vit.fc2.x", "vit.qkv.x", "vit.proj.x", "vit.patch")
+                    "other_kernels_single_stream": {t: rate(*single[t]) for t in ("vit.qkv", "vit.fc1", "vit.proj", "vit.fc1.x", "vit.fc2.x", "vit.qkv.x", "vit.proj.x", "vit.patch")
                                                     if t in single},
                     "frac_end_to_end": round(frac_e2e, 4),
                     "note": "achieved / frac = ALGORITHMIC FLOPs (2*M*N*K per launch; correction passes are never counted) / summed launch durations; "

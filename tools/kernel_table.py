@@ -16,19 +16,24 @@ M = 256 * 197                       # rows of a 256-tile step (one lane when str
 PEAK_TF, PEAK_HBM = 2516.6, 8000.0
 # kernel-name pattern -> (label, algorithmic FLOP per launch or None, algorithmic bytes per launch or None, roofline)
 G = lambda n, k: 2.0 * M * n * k
+# template arguments of gemm_f16_v2_kernel: <BN, WM, WN, NSTAGE, EPI, COMP (0 none | 1 W_lo term | 2 both terms), PERS>
 KERNELS = [
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, true>", "qkv GEMM (persistent, bias -> fp16)", G(3072, 1024), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "fc1 GEMM (persistent, bias + GELU -> fp16)", G(4096, 1024), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>", "proj / fc2 GEMM (persistent, LayerScale + fp32 residual RMW)", None, None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>", "fc1 GEMM + MX-fp4 correction phase", G(4096, 1024), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "fc2 GEMM + MX-fp4 correction phase", G(1024, 4096), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, false>", "qkv GEMM, split product (block 0: 3 fp16 passes)", G(3072, 1024), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, false>", "proj GEMM, split product (block 0)", G(1024, 1024), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 3, false, false>", "patch-embed GEMM, split product", 2.0 * 256 * 196 * 768 * 1024, None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, 0, true>", "qkv GEMM (persistent, bias -> fp16)", G(3072, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, 0, true>", "fc1 GEMM (persistent, bias + GELU -> fp16)", G(4096, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, 0, true>", "fc2 GEMM (persistent, LayerScale + fp32 residual RMW)", G(1024, 4096), None, "mfma"),
+    (r"gemm_f16_v2_kernel<128, 2, 2, 3, 2, 0, false>", "proj GEMM (256x128 tiles, two workgroups per CU, LayerScale + fp32 residual RMW)", G(1024, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, 2, false>", "fc1 GEMM + MX-fp4 correction phase (both terms)", G(4096, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, 2, false>", "fc2 GEMM + MX-fp4 correction phase (both terms)", G(1024, 4096), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, 2, false>", "qkv GEMM + MX-fp4 correction phase (block 0)", G(3072, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, 0, false>", "qkv GEMM, split product (3 fp16 passes)", G(3072, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, 0, false>", "proj GEMM, split product (block 0)", G(1024, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 3, 0, false>", "patch-embed GEMM, split product", 2.0 * 256 * 196 * 768 * 1024, None, "mfma"),
     (r"attention_pers_kernel<13>", "attention (197 tokens, 16 heads; persistent, next pair's K / V staged under the compute)", 4.0 * 256 * 16 * 197 * 197 * 64, 2.0 * M * 4096, "mfma"),
-    (r"attention_kernel<13, false, 8>", "attention (197 tokens, 16 heads)", 4.0 * 256 * 16 * 197 * 197 * 64, 2.0 * M * 4096, "mfma"),
+    (r"attention_kernel<13, false, 8>", "attention, last block (CLS query only)", None, None, "mfma"),
     (r"attention_kernel<13, true, 4>", "attention, split product (block 0)", 4.0 * 256 * 16 * 197 * 197 * 64, 4.0 * M * 4096, "mfma"),
-    (r"layernorm_blk_kernel<4, 8>", "LayerNorm (fp32 in, fp16 K-blocked out [+ lo / fp4 planes])", None, 6.0 * M * 1024, "hbm"),
+    (r"layernorm_blk_kernel<4, 8>", "LayerNorm (fp32 in, fp16 K-blocked out; the average includes the 256-row launches of the CLS-row path)", None, None, "hbm"),
+    (r"gemm_skinny_partial_kernel", "CLS rows: small-M GEMM, K-sliced partial products (fc1 / fc2 of the CLS-row path, last block's tail)", None, None, "mfma"),
+    (r"gemm_skinny_reduce", "CLS rows: partial-sum reduce + epilogue", None, None, "hbm"),
     (r"im2col_kernel", "im2col (+ cls / pos rows)", None, 256 * 3 * 224 * 224 * 2 + 2 * 2.0 * 256 * 196 * 768, "hbm"),
 ]
 
@@ -46,11 +51,6 @@ traffic = json.load(open(traffic_json))
 tr_by_pat = {v["kernel"]: v for v in traffic.values()}
 
 total_ns = sum(t for _, t, _ in stats.values())
-# the fp32-residual kernel serves proj (K = 1024) and fc2 (K = 4096): as many fc2 launches as plain fc1 launches, the rest are proj
-RES, FC1 = "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>", "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>"
-c_res = next((v[0] for n, v in stats.items() if RES in n), 0)
-c_fc1 = next((v[0] for n, v in stats.items() if FC1 in n), 0)
-res_flop_avg = ((c_res - c_fc1) * G(1024, 1024) + c_fc1 * G(1024, 4096)) / c_res if c_res > c_fc1 > 0 else None
 print("| kernel | launches / step | avg µs | % of step | algorithmic rate | frac of roofline | matrix pipe busy | eff. clock (MHz) | HBM-side bytes / launch (÷ algorithmic) |")
 print("|---|---|---|---|---|---|---|---|---|")
 seen = 0.0
@@ -61,9 +61,6 @@ for pat, label, flop, abytes, roof in KERNELS:
     name, (calls, tot, avg) = hit[0]
     seen += tot
     rate = frac = "—"
-    if pat == RES and res_flop_avg:
-        flop = res_flop_avg
-        label += f" [{(c_res - c_fc1) / steps:.0f} proj + {c_fc1 / steps:.0f} fc2 launches per step]"
     if roof == "mfma" and flop:
         tf = flop / avg / 1e3
         rate, frac = f"{tf:.0f} TFLOP/s", f"{tf / PEAK_TF:.3f}"
@@ -84,14 +81,8 @@ for pat, label, flop, abytes, roof in KERNELS:
     if t:
         tb = f"{t['bytes_per_launch'] / 1e6:.0f} MB" + (f" ({t['traffic_over_algorithmic']}x)" if "traffic_over_algorithmic" in t else "")
     print(f"| `{label}` | {calls / steps:.1f} | {avg / 1e3:.1f} | {100 * tot / total_ns:.1f} | {rate} | {frac} | {busy} | {clk} | {tb} |")
-    if pat == RES and bench_json:
-        by = json.load(open(bench_json))["roofline"].get("by_operator", {})
-        for op, what in (("vit.proj", "— of which proj [M,1024] x [1024,1024] (HIP events, bench.py single-stream pass)"), ("vit.fc2", "— of which fc2 [M,4096] x [4096,1024]")):
-            if op in by:
-                o = by[op]
-                print(f"| {what} | {o['launches'] / 3:.0f} | {o['avg_launch_ms'] * 1e3:.1f} | | {o['achieved']:.0f} TFLOP/s | {o['frac']:.3f} | | | |")
 print(f"| everything else | | | {100 * (total_ns - seen) / total_ns:.1f} | | | | | |")
 print(f"\nstep = {total_ns / steps / 1e6:.2f} ms of kernel time on one stream ({steps:.0f} steps profiled); peaks: {PEAK_TF} TFLOP/s dense fp16 at 2.4 GHz, {PEAK_HBM:.0f} GB/s HBM.")
 print("`matrix pipe busy` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); `eff. clock` = GRBM_GUI_ACTIVE / 8 / duration of the same dispatches "
       "(* = duration taken from the kernel-trace run: the counter CSV had no timestamps); counter-collecting runs serialise kernels and clock a little lower than plain ones. "
-      "traffic rows are measured on the two-lane run (128-tile launches: the ratio is what matters).")
+      "traffic rows: FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of the single-stream run (256-tile launches).")

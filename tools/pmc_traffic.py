@@ -17,23 +17,18 @@ def mean_per_kernel(path, counter):
 
 fetch = mean_per_kernel(sys.argv[1], "FETCH_SIZE")
 write = mean_per_kernel(sys.argv[2], "WRITE_SIZE")
-# template arguments: <BN, WM, WN, NSTAGE, EPI, COMP, PERS>
-TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, false, true>", "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, true, false>",
-        "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, false, true>", "vit.proj+fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, false, true>",
-        "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, true, false>", "vit.attn": "attention_pers_kernel<13>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
+# template arguments: <BN, WM, WN, NSTAGE, EPI, COMP (0 | 1 | 2), PERS>
+TAGS = {"vit.fc1": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, 0, true>", "vit.qkv": "gemm_f16_v2_kernel<256, 2, 4, 4, 0, 0, true>",
+        "vit.fc2": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, 0, true>", "vit.proj": "gemm_f16_v2_kernel<128, 2, 2, 3, 2, 0, false>",
+        "vit.fc1+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 1, 2, false>", "vit.fc2+mxfp4": "gemm_f16_v2_kernel<256, 2, 4, 4, 2, 2, false>",
+        "vit.attn": "attention_pers_kernel<13>", "vit.ln": "layernorm_blk_kernel<4, 8>"}
 # algorithmic bytes per launch of TILES tiles (argv[4], default 128 = one lane of the two-lane bench; 256 when the passes ran with --opt streams=1):
 # operands read once + outputs written once (+ fp32 residual read-modify-write)
 TILES = int(sys.argv[4]) if len(sys.argv) > 4 else 128
 M = TILES * 197
 ALGO = {"vit.fc1": 2 * (M * 1024 + 4096 * 1024) + 2 * M * 4096, "vit.qkv": 2 * (M * 1024 + 3072 * 1024) + 2 * M * 3072,
-        "vit.attn": 2 * M * 3072 + 2 * M * 1024, "vit.ln": 4 * M * 1024 + 2 * M * 1024}
-# the fp32-residual kernel is launched for proj (K = 1024) and fc2 (K = 4096): as many fc2 launches as plain fc1 launches, the rest are proj
-B_PROJ = 2 * (M * 1024 + 1024 * 1024) + 8 * M * 1024
-B_FC2 = 2 * (M * 4096 + 4096 * 1024) + 8 * M * 1024
-n_all = sum(n for k, (v, n) in fetch.items() if TAGS["vit.proj+fc2"] in k)
-n_fc2 = sum(n for k, (v, n) in fetch.items() if TAGS["vit.fc1"] in k)
-if n_all > n_fc2 > 0:
-    ALGO["vit.proj+fc2"] = round(((n_all - n_fc2) * B_PROJ + n_fc2 * B_FC2) / n_all)
+        "vit.attn": 2 * M * 3072 + 2 * M * 1024,
+        "vit.proj": 2 * (M * 1024 + 1024 * 1024) + 8 * M * 1024, "vit.fc2": 2 * (M * 4096 + 4096 * 1024) + 8 * M * 1024}
 out = {}
 for tag, pat in TAGS.items():
     f = [(v, n) for k, (v, n) in fetch.items() if pat in k]
@@ -44,7 +39,5 @@ for tag, pat in TAGS.items():
         if tag in ALGO:
             out[tag]["algorithmic_bytes_per_launch"] = ALGO[tag]
             out[tag]["traffic_over_algorithmic"] = round(out[tag]["bytes_per_launch"] / ALGO[tag], 2)
-        if tag == "vit.proj+fc2" and n_all > n_fc2 > 0:
-            out[tag]["launch_mix"] = {"proj": n_all - n_fc2, "fc2": n_fc2}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
