@@ -152,6 +152,7 @@ struct keep_handle {
         for (auto& c : cal) for (int k = 0; k < 4; ++k) { if (c.sum[k]) (void)hipFree(c.sum[k]); if (c.bias[k]) (void)hipFree(c.bias[k]); }
         cal.clear(); bias_ready = false;
     }
+    int patch_split = 1;         // 0: the patch-embedding GEMM as one fp16 pass (experiments; measured in profiles/r05_patch_embed_plain.txt)
     int cls_qkv = 0;             // 1: last ViT block (with cls_tail): the q part of the qkv GEMM for the CLS rows only (exact).  Measured (round 5, tools/ab_options.py):
                                  // vit.qkv -0.09 ms per step on one stream, +0.02 ms of small launches, 6041 vs 6044 tiles/s end to end with two lanes: below the
                                  // 0.3 % it would have to return -- off by default
@@ -452,9 +453,9 @@ struct VitLane {
 int vit_begin(keep_handle* h, VitLane& L) {
     const int D = h->vit_D, Bc = L.Bc;
     hipStream_t s = L.s; VitWs& ws = L.ws; const void* pixels = L.pixels; const int pix_dtype = L.pix_dtype;
-    // The patch embed is 0.25 % of the FLOPs but its rounding error feeds all 24 blocks: always run it
-    // as the hi/lo split product.
-    const bool sp0 = true;
+    // The patch embed is 0.25 % of the FLOPs but its rounding error feeds all 24 blocks: it runs as the hi/lo split product
+    // (option "patch_split" = 0, experiments: one fp16 pass -- KEEP_PREC_FP16 and KEEP_PREC_COMP only).
+    const bool sp0 = h->patch_split || h->precision == KEEP_PREC_STRICT || h->strict_blocks > 0;
     {
         Scope sc(h, T_VIT_IM2COL, s);
         launch_im2col(pixels, pix_dtype, Bc, ws.pat_hi, sp0 ? ws.pat_lo : nullptr,
@@ -1269,6 +1270,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
     else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
+    else if (n == "patch_split") { h->patch_split = v ? 1 : 0; }
     else if (n == "bias_correction") { h->bias_correction = v ? 1 : 0; }
     else if (n == "impl2128_mask") { if (v < 0 || v > 15) return h->fail(KEEP_EINVAL, "impl2128_mask must be 0..15"); h->impl2128_mask = v; }
     else if (n == "proj_impl") { if (v != 0 && v != 2128) return h->fail(KEEP_EINVAL, "proj_impl must be 0 or 2128"); h->proj_impl = v; }
@@ -1329,6 +1331,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "proj_impl") return h->proj_impl;
     if (n == "impl2128_mask") return h->impl2128_mask;
     if (n == "cls_qkv") return h->cls_qkv;
+    if (n == "patch_split") return h->patch_split;
     if (n == "bias_correction") return h->bias_correction;
     if (n == "bias_ready") return h->bias_ready ? 1 : 0;
     return -1;
