@@ -1282,7 +1282,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "lane_min_tiles") { if (v < 6) return h->fail(KEEP_EINVAL, "lane_min_tiles must be >= 6"); h->lane_min_tiles = v; }
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
     else if (n == "lane0_permille") { if (v < 100 || v > 900) return h->fail(KEEP_EINVAL, "lane0_permille must be 100..900"); h->lane0_permille = v; }
-    else if (n == "ln_impl") { if (v != 0 && v != 1) return h->fail(KEEP_EINVAL, "ln_impl must be 0 or 1"); t.ln_impl = v; }
+    else if (n == "ln_impl") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "ln_impl must be 0, 1 or 2"); t.ln_impl = v; }
     else if (n == "attn_waves") { if (v != 4 && v != 8 && v != 16) return h->fail(KEEP_EINVAL, "attn_waves must be 4, 8 or 16 (16: persistent double-buffered kernel for the image tower)"); t.attn_waves = v; }
     else if (n == "gemm_impl") {
         bool ok = v == 0 || v == 128 || v == 256;

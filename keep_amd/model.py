@@ -414,7 +414,8 @@ class KEEPModel:
     @torch.no_grad()
     def calibrate(self, n_tiles: int = 256, population: Optional[float] = None, tiles: Optional[torch.Tensor] = None,
                   text_features: Optional[torch.Tensor] = None, seed: int = 20250929, tolerance: float = TOLERANCE,
-                  confidence: float = CONFIDENCE, budget: Optional[str] = None, knobs: Optional[Mapping] = None) -> Optional[dict]:
+                  confidence: float = CONFIDENCE, budget: Optional[str] = None, knobs: Optional[Mapping] = None,
+                  label_population: Optional[float] = None) -> Optional[dict]:
         """Pick the 'comp' plan for THESE weights and for the population the model will be used on.
 
         A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded once with split
@@ -542,13 +543,15 @@ class KEEPModel:
             err, rms, pred, tail = chosen_stats
             # keep_classify looks a second time at tiles whose top-2 cosine margin could hide a flipped label.  A margin is the difference of two
             # cosines of ONE tile, i.e. its error vector projected on t1 - t2 (|t1 - t2| <= sqrt 2): standard deviation <= sqrt 2 x rms, not 2 x, and
-            # there are fewer margins (one per tile) than cosines -- so sqrt 2 x the predicted worst cosine error bounds it at the same confidence.
-            margin = math.sqrt(2.0) * pred
+            # there is ONE margin per tile: the quantile is taken over the tiles of the population (`label_population`; default: the 100 000 tiles of
+            # the default population, the whole population for a caller's own), at the same confidence.
+            n_margins = float(label_population) if label_population else (100_000.0 if population == float(CALIBRATION_POPULATION) else population)
+            margin = math.sqrt(2.0) * rms * PROBE_RMS_MARGIN * tail * max_sigmas_quantile(n_margins, confidence)
             self.set_option("label_margin", margin)
             self.calibration.update({"probe_max_abs_dcos": float(f"{err:.3e}"), "probe_rms_dcos": float(f"{rms:.3e}"), "tail_factor": round(tail, 3),
                                      "predicted_max_abs_dcos": float(f"{pred:.3e}"),
                                      "exceedance_probability": float(f"{exceedance_probability(rms * PROBE_RMS_MARGIN * tail, population, tolerance):.3e}"),
-                                     "label_margin": float(f"{margin:.3e}")})
+                                     "label_margin": float(f"{margin:.3e}"), "label_population": n_margins})
         if shares is not None:
             self.calibration["variance_shares"] = shares
         return self.calibration

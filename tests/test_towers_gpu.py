@@ -598,7 +598,7 @@ def test_config3_fixture_first_chunk(golden_dir):
         if precision == "comp":
             assert 0 < m.last_rechecked < chunk // 4
             lm = m.get_option("label_margin")                       # set by calibrate(): sqrt 2 x the predicted worst cosine error (<= 1.42e-4), not a fixed 2.5e-4
-            assert 5e-5 < lm <= 2 ** 0.5 * COS_TOL * 1.001
+            assert 5e-5 < lm <= 2 ** 0.5 * COS_TOL * 1.001 and lm == pytest.approx(m.calibration["label_margin"], rel=1e-3)
             flagged = (csim.topk(2, dim=1).values.diff(dim=1).abs().squeeze(1) < 0.9 * lm).cpu()      # rows that were looked at again carry strict-grade cosines
             assert (dc[flagged].max() < 5e-6) if flagged.any() else True
         else:
@@ -799,7 +799,9 @@ def test_calibrate_walks_its_candidates_and_reports(small, budget):
     for c in (lo, hi):
         if c["precision"] == "comp":
             assert c["exceedance_probability"] <= 1.0 - c["confidence"] + 1e-9
-            assert c["label_margin"] == pytest.approx(2 ** 0.5 * c["predicted_max_abs_dcos"], rel=1e-2)
+            from keep_amd.model import max_sigmas_quantile
+            z_ratio = max_sigmas_quantile(c["label_population"], c["confidence"]) / max_sigmas_quantile(c["population"], c["confidence"])
+            assert c["label_margin"] == pytest.approx(2 ** 0.5 * c["predicted_max_abs_dcos"] * z_ratio, rel=1e-2) and z_ratio <= 1.0
     if hi["precision"] == "comp":
         assert m.get_option("label_margin") == pytest.approx(hi["label_margin"], rel=1e-3)         # the last calibration set the engine's second-look threshold
     # strict_blocks set by the caller survives a calibration (it used to be reset to 0)
