@@ -152,7 +152,8 @@ int keep_bert_layers(keep_handle* h);
  *                     workgroup per CU walking the tile list, the next tile's first three K steps staged under the epilogue; 0: one
  *                     tile per workgroup.  Bit-identical results either way.
  *   "sgemv_m"         same for the few-row fp32 kernel of the projection head / pooler / similarity (default 16)
- *   "ln_impl"         1 (default) LayerNorm with LDS-transposed K-blocked stores | 0 per-row stores
+ *   "ln_impl"         2 (default) LayerNorm with LDS-transposed K-blocked stores from 4-wave workgroups (co-resident with the other lane's persistent fc1 GEMM:
+ *                     +0.3 % end to end) | 1 the same from 8-wave workgroups | 0 per-row stores.  Same results bit for bit.
  *   "attn_waves"      16 (default): image-tower attention of >= 512 (image, head) pairs on the persistent double-buffered kernel (bit-identical
  *                     to 8, the K / V staging of the next pair runs under the current one's compute), 8 waves per workgroup elsewhere | 8 | 4
  *   "lane0_permille", "lane_skew"   experiments with the two-lane schedule (defaults 500 / 0 measured best)

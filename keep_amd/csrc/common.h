@@ -71,7 +71,9 @@ struct KeepTune {
     int gemm_skinny_m = 320;     // calls with M <= this take the register-direct split-K kernel (0: never)
     int gemm_splitk_tiles = 64;  // a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never)
     int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
-    int ln_impl = 1;             // 1: LDS-transposed blk stores; 0: per-row stores
+    int ln_impl = 2;             // 2 (default): LDS-transposed blk stores from 4-wave workgroups (one 56-register wave per SIMD: fits beside two waves of the other lane's
+                                 //    persistent fc1 GEMM; +0.32 % end to end in a six-round rotated A/B, profiles/r05_ab_layernorm_workgroups.txt); 1: the same from 8-wave
+                                 //    workgroups (512-byte runs: 2 % faster alone); 0: per-row stores
     int attn_waves = 16;         // 16: image-tower calls with >= 512 (image, head) pairs take the persistent double-buffered kernel (13 compute + 3 loader waves),
                                  //     everything else 8 waves per workgroup; 8 / 4: one (image, head) pair per workgroup of that many waves
     int gemm_persistent = 1;     // 1: plain 256x256 GEMMs with more tiles than CUs run as one workgroup per CU walking the tile list, the next tile's

@@ -560,7 +560,7 @@ int launch_layernorm(const LnParams& p, hipStream_t s) {
     const bool blk_ok = p.out_kt > 0 && p.out_hi && (p.D == 1024 || p.D == 768) && p.out_kt == p.D / 32;
     if (p.out_q && !blk_ok) return -1;                  // the fp4 planes are only produced by the blk-layout kernel
     if (ln_impl == 2 && blk_ok && p.D == 1024 && !p.out_q) {
-        // experiment: 4-wave workgroups (4 rows, 256-byte runs): one wave of 56 registers per SIMD fits beside TWO 208-register waves of the other lane's persistent
+        // 4-wave workgroups (4 rows, 256-byte runs): one wave of 56 registers per SIMD fits beside TWO 208-register waves of the other lane's persistent
         // fc1 GEMM (an 8-wave LayerNorm workgroup needs 112 registers per SIMD and only fits beside the 200-register qkv kernel)
         constexpr int R = 4;
         const size_t lds = (size_t)R * (p.D + 32) * 2 * (p.out_lo ? 2 : 1);
