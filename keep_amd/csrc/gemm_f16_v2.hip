@@ -230,6 +230,14 @@ void gemm_f16_v2_kernel(GemmParams p) {
 
     f32x16 acc[TN][TM];
     long long t_start = 0, t_first = 0, t_loop = 0;
+#ifdef KEEP_DIAGNOSTICS
+    // ablate >> 8 = D: workgroups start (slot & 3) * D * 1024 cycles late -- four phase groups inside every XCD, so that their epilogues do not coincide
+    // (is a tile's epilogue shorter when the chip is not in its epilogue all at once?  tools/gemm_timeline.py)
+    if (p.ablate >> 8) {
+        const long long wait = (long long)((blockIdx.x >> 3) & 3) * (p.ablate >> 8) * 1024, t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     if (p.dbg) t_start = __builtin_readcyclecounter();
   for (;;) {                                               // one pass per tile; a non-persistent kernel leaves after the first
     if constexpr (PERS) {

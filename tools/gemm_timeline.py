@@ -3,7 +3,11 @@
 
 Needs a diagnostics build of the library (the timing / ablation hooks are compiled out of the product .so):
     KEEP_BUILD_DEFINES="-DKEEP_DIAGNOSTICS" KEEP_BUILD_OUT=libkeep_hip_diag.so python -m keep_amd.build
-    KEEP_HIP_LIB=$PWD/keep_amd/libkeep_hip_diag.so python tools/gemm_timeline.py
+    KEEP_HIP_LIB=$PWD/keep_amd/libkeep_hip_diag.so python tools/gemm_timeline.py [name=value engine options ...]
+
+    gemm_persistent=0|1      one tile per workgroup / the persistent walk (stamps then describe a workgroup's last tile)
+    gemm_ablate=$((D*256))   workgroups start (slot & 3) * D * 1024 cycles late: four phase groups inside every XCD (how long is an epilogue when the
+                             chip is not in its epilogue all at once?  profiles/r05_epilogue_dephasing.txt)
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
