@@ -234,7 +234,7 @@ def diff_stats(d):
 C4_SEEDS = (1000, 2000, 3000, 4000, 5000)        # tile seeds of the config-4 leg: each is a different 100 000-tile synthetic slide
 
 
-def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, topn: int = 50, settings=None, seeds=C4_SEEDS):
+def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, topn: int = 50, settings=None, seeds=C4_SEEDS, deadline=None):
     """BASELINE config 4 at its stated size on one GPU, on SEVERAL synthetic slides (`seeds`): n tiles (generated on the device, 256 per batch)
     encoded in the model's current 'comp' plan and in 'strict' (split products: pinned to 6.4e-7 of the fp32 oracle on config 3).  Per slide: every
     cosine difference against a 64-prompt bank (n x 64) and against the `distinct` prompt strings a K x 4 classifier bank of the RCC shape is built
@@ -282,6 +282,10 @@ def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, to
         txt64, txtD = text_banks()
         per_seed, strict_rates, comp_rates = [], [], []
         for si, seed in enumerate(seeds):
+            # the default run must end within minutes on any box: a slide takes ~50 s; the ones that would start past the budget are left out and named
+            if si > 0 and deadline is not None and time.perf_counter() - T_START > deadline:
+                out["slides_skipped"] = {"tile_seeds": list(seeds[si:]), "why": f"the run was {time.perf_counter() - T_START:.0f} s old (budget {deadline:.0f} s: --c4-budget-seconds)"}
+                break
             model.set_precision("strict", sb_was)
             f_s, t_s = encode_all(seed)
             strict_rates.append(n / t_s)
@@ -335,6 +339,7 @@ def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, to
                 r["prob_map_max_abs_diff"] = float(f"{float((p2 - p2_s).abs().max()):.3e}")
                 out["headline_setting" if pi == 0 else f"setting_{pi}_{plan_string(plan)}"] = r
         keyD = f"cos_vs_{distinct}_distinct_prompts"
+        out["slides_run"] = len(per_seed)
         out["strict_tiles_per_s"] = round(sum(strict_rates) / len(strict_rates), 1)
         out["tiles_per_s_incl_tile_generation"] = round(sum(comp_rates) / len(comp_rates), 1)
         out["per_seed"] = [{"tile_seed": r["tile_seed"], "cos_vs_64_prompts": r["cos_vs_64_prompts"], keyD: r[keyD],
@@ -386,6 +391,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the config-3 parity / config-3 / config-4 / config-5 legs")
     ap.add_argument("--no-c4", action="store_true", help="skip the 100 000-tile config-4 leg (about a minute)")
     ap.add_argument("--c4-tiles", type=int, default=100_000)
+    ap.add_argument("--c4-budget-seconds", type=float, default=240.0, help="no further config-4 slide is started once the run is this old (the first one always runs)")
     ap.add_argument("--c4-seeds", type=int, default=len(C4_SEEDS), help="number of 100 000-tile synthetic slides of the config-4 leg (about 50 s each)")
     ap.add_argument("--budget", default=None, choices=["ladder", "measured"], help="re-run KEEPModel.calibrate with this budget after loading")
     ap.add_argument("--plan", default=None, help="run this per-block plan instead of the calibrated one: the 'attn:<digits> mlp:<digits>' string a bench line "
@@ -567,7 +573,7 @@ def main():
             log(f"WARNING: {parity['argmax_mismatches']} config-3 labels differ from the fp32 oracle's -- the north star asks for bit-exact labels")
         if not args.no_c4 and args.precision == "comp":
             log(f"config 4 ({args.c4_tiles} tiles: the benched setting against the split-product mode) ...")
-            c4 = config4(model, dev, n=args.c4_tiles, seeds=C4_SEEDS[:max(1, args.c4_seeds)])
+            c4 = config4(model, dev, n=args.c4_tiles, seeds=C4_SEEDS[:max(1, args.c4_seeds)], deadline=args.c4_budget_seconds)
             if not c4["within_1e-4"]:
                 log("WARNING: config 4 holds cosines that differ from the split-product mode by more than 1e-4 in the benched setting")
         log("configs done")
