@@ -26,12 +26,13 @@ def main():
     ap.add_argument("--settings", nargs="*", default=["1,8", "1,10"], help="extra prefix plans (comp_full_blocks,comp_mlp_blocks) measured on the first slide")
     ap.add_argument("--seeds", type=int, default=5, help="number of synthetic slides (tile seeds 1000, 2000, ...)")
     ap.add_argument("--family", default="default", help="weight family of keep_amd.synth (default | heavy_tail | small_ls)")
+    ap.add_argument("--weight-seed", type=int, default=0, help="seed of the synthetic weights (bench.py runs seed 0)")
     ap.add_argument("--budget", default="ladder", choices=["ladder", "measured"])
     ap.add_argument("--out", default="gpurun_out/c4_parity.json")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     model = KEEPModel(KEEPShape())
-    model.load_state_dict(synth_state_dict(KEEPShape(), seed=0, family=args.family))
+    model.load_state_dict(synth_state_dict(KEEPShape(), seed=args.weight_seed, family=args.family))
     model.to(dev).eval()                                                  # calibrates: `headline_setting` below is what load_state_dict picked
     if args.budget != "ladder":
         model.calibrate(budget=args.budget)
@@ -39,6 +40,7 @@ def main():
     res = bench.config4(model, dev, n=args.tiles, settings=[tuple(int(v) for v in st.split(",")) for st in args.settings],
                         seeds=tuple(1000 * (i + 1) for i in range(args.seeds)))
     res["weight_family"] = args.family
+    res["weight_seed"] = args.weight_seed
     res["calibration"] = model.calibration
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(res, open(args.out, "w"), indent=1)
