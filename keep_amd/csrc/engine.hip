@@ -147,6 +147,7 @@ struct keep_handle {
     std::vector<SiteCal> cal;    // per ViT block; sites: 0 qkv, 1 proj, 2 fc1, 3 fc2
     bool capture = false;        // the running encode accumulates cal[i].sum
     bool bias_ready = false;     // cal[i].bias hold corrected biases for the loaded weights
+    int cal_cls_tail = 1;        // cls_tail at the time of the calibration (switching it afterwards invalidates the last block's averages)
     int bias_correction = 1;     // plain launches use them (0: the checkpoint's own biases)
     void free_cal() {
         for (auto& c : cal) for (int k = 0; k < 4; ++k) { if (c.sum[k]) (void)hipFree(c.sum[k]); if (c.bias[k]) (void)hipFree(c.bias[k]); }
@@ -1268,7 +1269,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "fused_screening") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "fused_screening must be 0..2"); h->fused_screening = v; }
     else if (n == "max_tiles") { if (v < 1) return h->fail(KEEP_EINVAL, "max_tiles < 1"); h->max_tiles = v; }
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
-    else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; }
+    else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; if (h->bias_ready && h->cal_cls_tail != h->cls_tail) h->bias_ready = false; }   // (the mean-input biases of the last block were averaged under the other setting: recalibrate)
     else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
     else if (n == "patch_split") { h->patch_split = v ? 1 : 0; }
     else if (n == "bias_correction") { h->bias_correction = v ? 1 : 0; }
@@ -1447,18 +1448,26 @@ int keep_calibrate_bias(keep_handle* h, const void* pixels, int pix_dtype, int64
     ++h->opt_epoch;
     const int D = h->vit_D, F = h->vit_F;
     const int widths[4] = {D, D, D, F}, outs[4] = {3 * D, D, F, D};
+    h->bias_ready = false;
     if ((int)h->cal.size() != h->vit_depth) {
         h->free_cal();
         h->cal.resize(h->vit_depth);
+        bool ok = true;
         for (auto& c : h->cal)
-            for (int k = 0; k < 4; ++k) {
-                HIPCHK(h, hipMalloc(&c.sum[k], widths[k] * sizeof(float)));
-                HIPCHK(h, hipMalloc(&c.bias[k], outs[k] * sizeof(float)));
-            }
+            for (int k = 0; k < 4 && ok; ++k)
+                ok = hipMalloc(&c.sum[k], widths[k] * sizeof(float)) == hipSuccess && hipMalloc(&c.bias[k], outs[k] * sizeof(float)) == hipSuccess;
+        if (!ok) {                                   // never leave a half-allocated table behind: the next call would skip the allocation
+            (void)hipGetLastError();
+            h->free_cal();
+            return h->fail(KEEP_ENOMEM, "bias calibration: out of device memory");
+        }
     }
     for (auto& c : h->cal)
-        for (int k = 0; k < 4; ++k) { HIPCHK(h, hipMemsetAsync(c.sum[k], 0, widths[k] * sizeof(float), s)); c.rows[k] = 0; }
-    h->bias_ready = false;
+        for (int k = 0; k < 4; ++k) {
+            if (hipMemsetAsync(c.sum[k], 0, widths[k] * sizeof(float), s) != hipSuccess) { (void)hipGetLastError(); h->free_cal(); return h->fail(KEEP_EHIP, "bias calibration: memset failed"); }
+            c.rows[k] = 0;
+        }
+    h->cal_cls_tail = h->cls_tail;                   // the last block's sites 1-3 average the CLS rows only when cls_tail is on: the biases belong to that setting
     float* scratch = nullptr;
     HIPCHK(h, hipMalloc(&scratch, (size_t)B * h->proj_dim * sizeof(float)));
     // one lane, no graph replay: every site is visited once per sub-batch, on ONE stream, so the sums accumulate in a fixed order

@@ -787,9 +787,10 @@ int launch_gemm_f16_v2(const GemmParams& p, int epi, int variant, hipStream_t s)
     }
     if (epi == EPI_TOP2) return p.N % 256 ? 1 : launch_v2_one<256, 2, 4, 4, EPI_TOP2, 0>(p, s);
     if (p.impl_hint == 2128 && p.nseg == 1 && !p.out_lo && !p.out_q && p.N % 128 == 0 && (p.N / 128) * ((p.M + V2_BM - 1) / V2_BM) > 2 * keep_num_cus()) {
-        if (epi == EPI_RESID_LS) return launch_v2_one<128, 2, 2, 3, EPI_RESID_LS, 0>(p, s);
-        if (epi == EPI_F16) return launch_v2_one<128, 2, 2, 3, EPI_F16, 0>(p, s);
-        if (epi == EPI_GELU_F16) return launch_v2_one<128, 2, 2, 3, EPI_GELU_F16, 0>(p, s);
+        // (taken only when the launch goes through: a device that refuses the dynamic-LDS opt-in falls through to the selection below, as launch_v2_pers does)
+        if (epi == EPI_RESID_LS && launch_v2_one<128, 2, 2, 3, EPI_RESID_LS, 0>(p, s) == 0) return 0;
+        if (epi == EPI_F16 && launch_v2_one<128, 2, 2, 3, EPI_F16, 0>(p, s) == 0) return 0;
+        if (epi == EPI_GELU_F16 && launch_v2_one<128, 2, 2, 3, EPI_GELU_F16, 0>(p, s) == 0) return 0;
     }
     if (variant == 256 && p.N % 256 == 0 && p.tune && p.tune->gemm_persistent && p.nseg == 1 && !p.out_lo && !p.out_q && p.K % 128 == 0 && p.K >= 256 &&
         (p.N / 256) * ((p.M + V2_BM - 1) / V2_BM) > keep_num_cus()) {

@@ -119,6 +119,39 @@ def exceedance_probability(rms: float, n: float, tolerance: float = TOLERANCE) -
     return float(-math.expm1(max(float(n), 1.0) * math.log1p(-tail)))
 
 
+def mixture_exceedance(sigmas: Sequence[float], n: float, x: float) -> float:
+    """P(at least one of n independent zero-mean Gaussian errors exceeds x in magnitude) when the errors' standard deviations are spread like
+    ``sigmas`` (each value standing for n / len(sigmas) samples): 1 - prod_i (1 - erfc(x / (sigma_i sqrt 2)))^(n / len).  Tiles are not equally hard
+    (a tile with more texture carries a larger error vector): the worst of a population is set by its hardest tiles, not by the rms over all."""
+    sig = [s for s in sigmas if s > 0.0]
+    if not sig:
+        return 0.0
+    w = max(float(n), 1.0) / len(sigmas)
+    acc = 0.0
+    for s in sig:
+        tail = math.erfc(x / (s * math.sqrt(2.0)))
+        if tail >= 1.0:
+            return 1.0
+        acc += w * math.log1p(-tail)
+    return float(-math.expm1(acc))
+
+
+def mixture_max_quantile(sigmas: Sequence[float], n: float, q: float = CONFIDENCE) -> float:
+    """x with P(max of the n errors <= x) = q under the mixture of ``mixture_exceedance`` (bisection); for equal sigmas this is
+    sigma x max_sigmas_quantile(n, q)."""
+    top = max(sigmas) if len(sigmas) else 0.0
+    if not top > 0.0:
+        return 0.0
+    lo, hi = 0.0, 40.0 * top
+    for _ in range(100):
+        mid = 0.5 * (lo + hi)
+        if mixture_exceedance(sigmas, n, mid) > 1.0 - q:
+            lo = mid
+        else:
+            hi = mid
+    return 0.5 * (lo + hi)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -172,9 +205,16 @@ class KEEPModel:
         # (about 2 s at load for ViT-L); "ladder": the prefix family COMP_LADDER only (under 1 s, up to 12 % slower plans -- profiles/r05_precision_budget.md)
         self.calibration_budget = os.environ.get("KEEP_CALIBRATION_BUDGET", "measured")
         self.calibration: Optional[dict] = None
+        # what calibrate() / calibrate_bias() probe when the caller passes no tiles: "mixture" = N(0,1) pixels AND the structured tile families of
+        # keep_amd.synth.calibration_probe, the plan being held to the WORST family; "gaussian" = N(0,1) pixels only (round 5's probe: it does not
+        # hold the tolerance on structured tiles -- profiles/r06_offdist_parity_before_repair_gaussian_probe.json)
+        self.calibration_probe = os.environ.get("KEEP_CALIBRATION_PROBE", "mixture")
         # load_state_dict on a GPU also runs calibrate_bias(): the mean-input compensation of the weight-rounding error that the plain fp16 launches use
         # (keep_calibrate_bias; KEEP_BIAS_CORRECTION=0 / bias_correction=False: the checkpoint's own biases everywhere)
-        self.bias_correction = os.environ.get("KEEP_BIAS_CORRECTION", "1") != "0"
+        # Round 6: OFF by default.  The correction is exact for the mean input row of the tiles it was calibrated on and only for it: calibrated on N(0,1)
+        # tiles it adds error on glass background, calibrated on the mixture probe it adds error on N(0,1) tiles, and the plan calibrate() then needs
+        # is dearer with it than without (profiles/r06_offdist_parity_*.json).  A caller who knows their tiles opts in: calibrate_bias(tiles=own) + calibrate(tiles=own).
+        self.bias_correction = os.environ.get("KEEP_BIAS_CORRECTION", "0") != "0"
         self.trim_padding = True      # encode_text at the longest valid length instead of the padded one (same result)
         self.last_text_length = 0     # T the text tower actually ran at in the last encode_text call
 
@@ -311,6 +351,7 @@ class KEEPModel:
                 raise RuntimeError("Error(s) in loading state_dict for KEEPModel:\n\tMissing key(s) in state_dict: " + ", ".join(missing)
                                    + ' (construct with towers=("image",) / ("text",) for a single-tower engine)')
         self._loaded = True
+        self._label_margin_unit = None
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1      # invalidates per-model prompt caches (keep_amd.wsi)
         self.calibration = None
         if self.auto_calibrate and lib.keep_vit_depth(h) > 0:
@@ -355,6 +396,8 @@ class KEEPModel:
 
     def set_option(self, name: str, value: float):
         self._options[name] = value
+        if name == "label_margin":
+            self._label_margin_unit = None        # an explicit threshold replaces the calibrated, bank-scaled one
         if name in self._PLAN_SHORTHANDS:
             self._plan = None                 # the engine rewrites the whole per-block plan from the shorthands
         if self._handle.value:
@@ -370,7 +413,9 @@ class KEEPModel:
         pre = plan_prefix(plan)
         for k in self._PLAN_SHORTHANDS:
             self._options.pop(k, None)
-        if pre is not None:                   # a prefix plan is stored as its shorthand (and reads back through get_option)
+        if pre is not None:                   # a prefix plan is stored as its shorthand (and reads back through get_option); the handle's qkv
+            # variants of the shorthand are reset first, so that what the engine rebuilds from the prefix is exactly `plan`
+            self._options["comp_qkv"], self._options["comp_qkv_from"] = 0, 1 << 20
             self._options["comp_full_blocks"], self._options["comp_mlp_blocks"] = pre
             self._plan = None
         else:
@@ -392,16 +437,27 @@ class KEEPModel:
         return out
 
     @torch.no_grad()
-    def calibrate_bias(self, tiles: Optional[torch.Tensor] = None, n_tiles: int = 64, seed: int = 20250936) -> "KEEPModel":
-        """Mean-input compensation of the weight-rounding error (``keep_calibrate_bias``): the engine encodes ``tiles`` (default ``n_tiles`` seeded N(0,1)
-        tiles; pass tiles of the caller's own distribution for a closer mean) in split products, averages the input rows of every GEMM of the image
-        tower and folds ``W_lo @ mean_input`` into the bias its plain fp16 launches use -- the row-independent part of the term a single fp16 pass drops,
-        10-50 % of a GEMM's weight-rounding variance, at no cost per call.  ``tiles`` of zero length forgets the calibration."""
+    def calibrate_bias(self, tiles: Optional[torch.Tensor] = None, n_tiles: int = 64, seed: int = 20250936, probe: Optional[str] = None) -> "KEEPModel":
+        """Mean-input compensation of the weight-rounding error (``keep_calibrate_bias``): the engine encodes ``tiles`` in split products, averages the
+        input rows of every GEMM of the image tower and folds ``W_lo @ mean_input`` into the bias its plain fp16 launches use -- the row-independent
+        part of the term a single fp16 pass drops, at no cost per call.  The correction is exact for the MEAN input row of ``tiles`` and only for it:
+        pass tiles of the caller's own distribution for a closer mean.  Default (``probe="mixture"``): ``n_tiles`` tiles of
+        ``keep_amd.synth.calibration_probe`` (N(0,1) pixels and the structured families in equal parts; round 6 -- calibrated on N(0,1) tiles alone
+        (``probe="gaussian"``, what round 5 did) the compensation ADDS error on near-constant background tiles,
+        profiles/r06_offdist_parity_before_repair_gaussian_probe.json).  ``calibrate()`` verifies whatever this leaves, family by family.  ``tiles`` of
+        zero length forgets the calibration."""
         self._ready()
         dev = self._device
         if tiles is None:
-            g = torch.Generator(device=dev).manual_seed(seed)
-            tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+            probe = probe or self.calibration_probe
+            if probe == "gaussian":
+                g = torch.Generator(device=dev).manual_seed(seed)
+                tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+            elif probe == "mixture":
+                from .synth import PROBE_FAMILIES, calibration_probe
+                tiles = calibration_probe(max(n_tiles // len(PROBE_FAMILIES), 1), dev, seed=seed)[0]
+            else:
+                raise ValueError("probe must be 'mixture' or 'gaussian'")
         x = tiles.to(dev)
         if x.dtype not in _PIX and x.dtype != torch.uint8:
             x = x.to(torch.float32)
@@ -412,28 +468,41 @@ class KEEPModel:
         return self
 
     @torch.no_grad()
-    def calibrate(self, n_tiles: int = 256, population: Optional[float] = None, tiles: Optional[torch.Tensor] = None,
+    def calibrate(self, n_tiles: int = 1024, population: Optional[float] = None, tiles: Optional[torch.Tensor] = None,
                   text_features: Optional[torch.Tensor] = None, seed: int = 20250929, tolerance: float = TOLERANCE,
                   confidence: float = CONFIDENCE, budget: Optional[str] = None, knobs: Optional[Mapping] = None,
-                  label_population: Optional[float] = None) -> Optional[dict]:
+                  label_population: Optional[float] = None, groups: Optional[torch.Tensor] = None, group_names: Optional[Sequence[str]] = None,
+                  probe: Optional[str] = None) -> Optional[dict]:
         """Pick the 'comp' plan for THESE weights and for the population the model will be used on.
 
-        A probe batch (``tiles``, default ``n_tiles`` seeded N(0,1) tiles -- what ImageNet-normalised pixels look like) is encoded once with split
-        products (the engine's fp32-class arithmetic, ~5e-7 from the fp32 reference) and then with candidate plans from the cheapest up.  Kept: the
-        first plan whose cosine errors over probe tiles x prompts predict, with probability ``confidence`` (0.99), a worst error <= ``tolerance``
-        (1e-4) over ``population`` cosines (tiles x distinct prompts the caller will compare; default ``CALIBRATION_POPULATION`` = a 100 000-tile
-        slide x the 264 distinct prompts of the RCC bank, BASELINE config 4):
+        A probe batch is encoded once with split products (the engine's fp32-class arithmetic, ~5e-7 from the fp32 reference) and then with candidate
+        plans from the cheapest up.  Kept: the first plan whose cosine errors over probe tiles x prompts predict, with probability ``confidence``
+        (0.99), a worst error <= ``tolerance`` (1e-4) over ``population`` cosines (tiles x distinct prompts the caller will compare; default
+        ``CALIBRATION_POPULATION`` = a 100 000-tile slide x the 264 distinct prompts of the RCC bank, BASELINE config 4):
 
-            rms x PROBE_RMS_MARGIN x max_sigmas_quantile(population, confidence) x tail <= tolerance
+            max over tile groups g of  mixture_max_quantile({sigma_t : t in g}, population, confidence) <= tolerance,
+            sigma_t = (isotropic error of probe tile t) x anisotropy x margin_g x tail_g
 
-        ``rms`` = the larger of (a) the rms cosine error against the probe's prompt bank and (b) the ISOTROPIC figure |feature error| / sqrt(D) -- what
-        the rms would be against prompts in random directions.  Error vectors are not isotropic, so a bank can see 5-10 % less (or more) than another
-        (measured: 1.48e-5 against the probe bank, 1.60e-5 against two other banks and isotropically, same plan); holding the plan to both keeps the
-        choice from leaning on one bank's luck.  ``tail`` >= 1 only when the probe's own maximum is larger than a Gaussian sample of its size allows at 99 % (heavier tails than the model
-        assumes).  ``model.calibration`` reports the prediction and the ``exceedance_probability`` of the chosen plan.  Candidates: ``budget="ladder"``
-        walks ``COMP_LADDER`` (prefix plans); ``budget="measured"`` first measures, on these weights, the variance share of every block's attention
-        side and MLP (one split-product encode per block and half with that one site downgraded), then builds the plan greedily by share / cost
-        (``KNOB_COST_MS``) and verifies it the same way.  The prompts are ``text_features`` ([P,768] unit rows -- pass the caller's own bank to
+        i.e. the ``confidence`` quantile of the largest of ``population`` Gaussian errors whose standard deviations are spread like the group's
+        per-tile errors (tiles are not equally hard; for equal sigmas this is rms x max_sigmas_quantile(population, confidence)).
+
+        The probe: ``tiles`` (with ``groups``, an int64 group index per tile, when they come from several distributions) or, by default
+        (``probe="mixture"``), ``n_tiles`` tiles of ``keep_amd.synth.calibration_probe`` -- N(0,1) pixels (BASELINE config 2) and the structured
+        families (stain fields, glass background, half / half) in equal parts, one group each.  The plan is held to the WORST group: a slide can be
+        all tissue or mostly glass, and rounding errors behave differently there -- on spatially correlated tiles most of the error vector is COMMON
+        to the tiles of a family (it does not average out across rows in attention, and the knobs that fix N(0,1) tiles leave it alone; round 6,
+        profiles/r06_offdist_parity_*.json).  ``probe="gaussian"`` = round 5's probe.
+
+        ``rms_g`` = the group's ISOTROPIC rms |feature error| / sqrt(D) -- what the rms would be against prompts in random directions -- times one
+        anisotropy factor for the plan: the median over the groups of (rms against the probe's prompt bank / isotropic rms), at least 1 (error
+        vectors are not isotropic; but the bank rms of a group of near-identical tiles is one random draw, so no single group's ratio is trusted).
+        ``margin_g`` >= PROBE_RMS_MARGIN = two standard errors of the group's mean squared error, estimated from its tile-to-tile spread (one tile's
+        cosines share ONE error vector).  ``tail_g`` >= 1 only when the group's own maximum is larger than a Gaussian sample of its size allows at
+        99 %.  ``model.calibration`` reports the prediction, the per-group figures and the ``exceedance_probability`` of the chosen plan.
+        Candidates: ``budget="ladder"`` walks ``COMP_LADDER`` (prefix plans); ``budget="measured"`` first measures, on these weights and per group,
+        the variance share of every block's attention side and MLP (one split-product encode per block and half with that one site downgraded),
+        then builds the plan greedily -- each step the upgrade that lowers the worst group's predicted variance most per millisecond
+        (``KNOB_COST_MS``) -- and verifies it the same way.  The prompts are ``text_features`` ([P,768] unit rows -- pass the caller's own bank to
         calibrate against it; default: 64 seeded prompts through the loaded text tower, or 64 seeded random unit vectors for an image-only engine,
         a harsher yardstick).  If nothing qualifies the engine switches to 'strict'.  ``label_margin`` (keep_classify's second-look threshold) is set
         from the measured rms.  Non-finite probe features (an activation beyond the fp16 range) raise FloatingPointError.  ``strict_blocks`` is
@@ -450,10 +519,31 @@ class KEEPModel:
             raise ValueError("budget must be 'ladder' or 'measured'")
         dev, depth = self._device, int(lib.keep_vit_depth(h))
         population = float(CALIBRATION_POPULATION if population is None else population)
+        probe_name = "caller's tiles"
         if tiles is None:
-            g = torch.Generator(device=dev).manual_seed(seed)
-            tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+            probe_name = probe or self.calibration_probe
+            if probe_name == "gaussian":
+                g = torch.Generator(device=dev).manual_seed(seed)
+                tiles = torch.randn(n_tiles, 3, 224, 224, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+                groups, group_names = None, ("gaussian",)
+            elif probe_name == "mixture":
+                from .synth import PROBE_FAMILIES, calibration_probe
+                tiles, groups, group_names = calibration_probe(max(n_tiles // len(PROBE_FAMILIES), 1), dev, seed=seed)
+            else:
+                raise ValueError("probe must be 'mixture' or 'gaussian'")
         tiles = tiles.to(dev)
+        n_t = int(tiles.shape[0])
+        if groups is None:
+            groups = torch.zeros(n_t, dtype=torch.int64)
+        groups = torch.as_tensor(groups, dtype=torch.int64).cpu()
+        if groups.numel() != n_t or (n_t and int(groups.min()) < 0):
+            raise ValueError("groups: one non-negative group index per probe tile")
+        n_groups = int(groups.max()) + 1 if n_t else 1
+        names = tuple(group_names) if group_names is not None else tuple(f"group{i}" for i in range(n_groups))
+        if len(names) < n_groups:
+            raise ValueError("group_names: one name per group index")
+        members = [torch.nonzero(groups == gi).flatten().to(dev) for gi in range(n_groups)]
+        members = [(names[gi], m) for gi, m in enumerate(members) if m.numel() > 0]
         if text_features is None:
             if lib.keep_bert_layers(h) > 0:
                 from .synth import synth_prompts
@@ -464,9 +554,7 @@ class KEEPModel:
                 text_features = torch.randn(64, self.config.projection_dim, generator=g).to(dev)
                 _lib.check(h, lib.keep_op_l2norm(h, _ptr(text_features), 64, self.config.projection_dim, _stream(dev)), "l2norm")
         bank = text_features.to(dev, torch.float32).contiguous()
-        n_probe = tiles.shape[0] * bank.shape[0]
         z_pop = max_sigmas_quantile(population, confidence)
-        z_probe99 = max_sigmas_quantile(n_probe, 0.99)
         rms_target = tolerance / (z_pop * PROBE_RMS_MARGIN)
         saved_opts, saved_plan = dict(self._options), (list(self._plan) if self._plan is not None else None)
         strict_blocks = int(saved_opts.get("strict_blocks") or 0)
@@ -474,32 +562,70 @@ class KEEPModel:
         tried, chosen, chosen_stats, shares = [], None, None, None
         done = False
 
-        def probe(plan: Plan):
-            """Encode the probe under `plan`; (max, rms, predicted population maximum at the confidence level, tail factor, bank rms, isotropic rms)."""
+        def encode_probe(x):
+            return torch.cat([self.encode_image(x[i:i + 256]) for i in range(0, x.shape[0], 256)]) if x.shape[0] > 256 else self.encode_image(x)
+
+        def probe_stats(plan: Plan):
+            """Encode the probe under `plan`; per group: max, isotropic and bank rms, margin, tail -> the governing group's figures."""
             self.set_plan(plan)
-            f = self.encode_image(tiles)
-            d = self.similarity(f, bank).sub_(ref).abs_()
-            err, rms_bank = float(d.max()), float(d.pow(2).mean().sqrt())
-            rms_iso = float((f - ref_f).pow(2).sum(dim=1).mean().div(f.shape[1]).sqrt())
-            rms = max(rms_bank, rms_iso)
-            tail = max(1.0, (err / rms_bank) / z_probe99) if rms_bank > 0 else 1.0
-            return err, rms, rms * PROBE_RMS_MARGIN * z_pop * tail, tail, rms_bank, rms_iso
+            f = encode_probe(tiles)
+            d2 = self.similarity(f, bank).sub_(ref).pow_(2)                    # [n, P] squared cosine errors
+            e2 = (f - ref_f).pow(2).sum(dim=1).div_(f.shape[1])               # [n] isotropic squared error per tile
+            rows = []
+            for name, idx in members:
+                dg, eg = d2[idx], e2[idx]
+                nt = int(idx.numel())
+                mx = float(dg.max().sqrt())
+                rms_bank, ms_iso = math.sqrt(float(dg.mean())), float(eg.mean())
+                rms_iso = math.sqrt(ms_iso)
+                # relative standard error of the group's mean squared error from its tile-to-tile spread (one tile's cosines share ONE error vector:
+                # the tile is the sample); the rule holds the plan to two of them, at least PROBE_RMS_MARGIN
+                se = float(eg.std()) / math.sqrt(nt) / ms_iso if nt > 1 and ms_iso > 0 else 0.0
+                margin = max(PROBE_RMS_MARGIN, math.sqrt(1.0 + 2.0 * se))
+                tail = max(1.0, (mx / rms_bank) / max_sigmas_quantile(nt * bank.shape[0], 0.99)) if rms_bank > 0 else 1.0
+                rows.append([name, mx, rms_bank, rms_iso, margin, tail, nt])
+            # error vectors are not isotropic: against a bank of real prompts the rms can sit 5-10 % above (or below) the isotropic figure.  ONE
+            # factor for the plan, the MEDIAN over the groups of bank rms / isotropic rms, at least 1: a group of near-identical tiles (glass) has
+            # near-identical error vectors, and against a bank of similar prompts its bank rms is a single random draw, not an rms
+            ratios = sorted(r[2] / r[3] for r in rows if r[3] > 0)
+            aniso = max(1.0, 0.5 * (ratios[(len(ratios) - 1) // 2] + ratios[len(ratios) // 2])) if ratios else 1.0
+            per_group, worst = {}, None
+            for (name, mx, rms_bank, rms_iso, margin, tail, nt), (_, idx) in zip(rows, members):
+                rms = rms_iso * aniso
+                # the group's tiles are not equally hard: the population maximum is predicted from the per-tile spread (mixture_max_quantile),
+                # every tile's isotropic error standing for population / nt cosines; `eff` = the homoscedastic rms that predicts the same maximum
+                sig = (e2[idx].double().sqrt() * (aniso * margin * tail)).tolist()
+                pred_g = mixture_max_quantile(sig, population, confidence)
+                eff = pred_g / z_pop
+                per_group[name] = {"max_abs_dcos": float(f"{mx:.3e}"), "rms_dcos_vs_bank": float(f"{rms_bank:.3e}"), "rms_dcos_isotropic": float(f"{rms_iso:.3e}"),
+                                   "margin": round(margin, 4), "tail_factor": round(tail, 3), "effective_rms": float(f"{eff:.3e}"),
+                                   "hardest_tile_over_rms": round(max(sig) / (rms * margin * tail), 3) if rms > 0 else 0.0, "tiles": nt,
+                                   "exceedance_probability": float(f"{mixture_exceedance(sig, population, tolerance):.3e}")}
+                if worst is None or eff > worst[1]:
+                    worst = (name, eff, mx, rms, margin, tail, rms_bank, rms_iso, sig)
+            per_group["anisotropy_factor"] = round(aniso, 4)
+            err_all = max(r[1] for r in rows)
+            return err_all, worst, per_group
 
         def consider(plan: Plan) -> bool:
             nonlocal chosen, chosen_stats
-            err, rms, pred, tail, rms_bank, rms_iso = probe(plan)
+            err, worst, per_group = probe_stats(plan)
+            name, eff, _, rms, margin, tail, rms_bank, rms_iso, sig = worst
+            pred = eff * z_pop
             pre = plan_prefix(plan)
             tried.append({"comp_full_blocks": pre[0] if pre else None, "comp_mlp_blocks": pre[1] if pre else None, "plan": plan_string(plan),
                           "max_abs_dcos": float(f"{err:.3e}"), "rms_dcos": float(f"{rms:.3e}"), "rms_dcos_vs_bank": float(f"{rms_bank:.3e}"),
-                          "rms_dcos_isotropic": float(f"{rms_iso:.3e}"), "predicted_max_abs_dcos": float(f"{pred:.3e}")})
+                          "rms_dcos_isotropic": float(f"{rms_iso:.3e}"), "governing_group": name, "predicted_max_abs_dcos": float(f"{pred:.3e}"),
+                          "isotropic_rms_by_group": {k: v["rms_dcos_isotropic"] for k, v in per_group.items() if isinstance(v, dict)},
+                          "anisotropy_factor": per_group["anisotropy_factor"]})
             if pred <= tolerance:                 # (NaN compares False: falls through to the next candidate)
-                chosen, chosen_stats = plan, (err, rms, pred, tail)
+                chosen, chosen_stats = plan, (err, rms, pred, tail, margin, name, per_group, sig)
                 return True
             return False
 
         try:
             self.set_precision("strict", strict_blocks)
-            ref_f = self.encode_image(tiles)
+            ref_f = encode_probe(tiles)
             ref = self.similarity(ref_f, bank)                              # cosines on the engine's exact-fp32 similarity kernel
             self.set_precision("comp", strict_blocks)
             if not bool(torch.isfinite(ref).all()):
@@ -509,8 +635,15 @@ class KEEPModel:
                     if consider(prefix_plan(depth, full, mlp)):
                         break
             else:
-                n_sh = min(tiles.shape[0], 64)             # the shares only rank the knobs: a quarter of the probe is enough (and 4 x faster)
-                shares = self._measure_shares(tiles[:n_sh], ref_f[:n_sh], depth)
+                # the shares only rank the knobs: an eighth of the probe (at least 16 tiles of every group) is enough, and 8 x faster
+                sel = torch.cat([idx[:max(16, int(idx.numel()) // 8)] for _, idx in members])
+                sh_members = []
+                at = 0
+                for name, idx in members:
+                    k = min(max(16, int(idx.numel()) // 8), int(idx.numel()))
+                    sh_members.append((name, torch.arange(at, at + k, device=dev)))
+                    at += k
+                shares = self._measure_shares(tiles[sel], ref_f[sel], depth, sh_members)
                 walk = self._greedy_walk(shares, depth, knobs or DEFAULT_KNOBS)
                 # the sum of measured shares over-predicts the rms of a plan by 3-11 % (variances of neighbouring sites do not quite add): start the
                 # verification a little before the predicted crossing and walk up one knob at a time until a plan verifies
@@ -537,35 +670,46 @@ class KEEPModel:
                             "population": population, "confidence": confidence, "max_sigmas_quantile": round(z_pop, 3),
                             "expected_max_sigmas": round(expected_max_sigmas(population), 3),
                             "target_rms_dcos": float(f"{rms_target:.3e}"), "strict_blocks": strict_blocks,
-                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts vs the split-product arithmetic", "tried": tried,
+                            "probe": f"{tiles.shape[0]} tiles x {bank.shape[0]} prompts vs the split-product arithmetic", "probe_distribution": probe_name,
+                            "probe_groups": [name for name, _ in members], "tried": tried,
                             "bias_correction": bool(lib.keep_get_option(h, b"bias_ready") > 0 and lib.keep_get_option(h, b"bias_correction") > 0)}
         if chosen:
-            err, rms, pred, tail = chosen_stats
+            err, rms, pred, tail, margin_g, gov, per_group, sig = chosen_stats
             # keep_classify looks a second time at tiles whose top-2 cosine margin could hide a flipped label.  A margin is the difference of two
-            # cosines of ONE tile, i.e. its error vector projected on t1 - t2 (|t1 - t2| <= sqrt 2): standard deviation <= sqrt 2 x rms, not 2 x, and
-            # there is ONE margin per tile: the quantile is taken over the tiles of the population (`label_population`; default: the 100 000 tiles of
-            # the default population, the whole population for a caller's own), at the same confidence.
+            # cosines of ONE tile, i.e. its error vector projected on t1 - t2: standard deviation |t1 - t2| x rms, and there is ONE margin per tile:
+            # the quantile is taken over the tiles of the population (`label_population`; default: the 100 000 tiles of the default population, the
+            # whole population for a caller's own), at the same confidence.  |t1 - t2| <= 2 in general; the engine's default is sqrt 2 (prompts
+            # with a non-negative cosine -- every pair of the banks this repository has seen); ``classify`` scales it by the caller's own bank.
             n_margins = float(label_population) if label_population else (100_000.0 if population == float(CALIBRATION_POPULATION) else population)
-            margin = math.sqrt(2.0) * rms * PROBE_RMS_MARGIN * tail * max_sigmas_quantile(n_margins, confidence)
+            unit = mixture_max_quantile(sig, n_margins, confidence)
+            margin = math.sqrt(2.0) * unit
             self.set_option("label_margin", margin)
+            self._label_margin_unit = unit
             self.calibration.update({"probe_max_abs_dcos": float(f"{err:.3e}"), "probe_rms_dcos": float(f"{rms:.3e}"), "tail_factor": round(tail, 3),
+                                     "rms_margin": round(margin_g, 4), "governing_group": gov, "per_group": per_group,
                                      "predicted_max_abs_dcos": float(f"{pred:.3e}"),
-                                     "exceedance_probability": float(f"{exceedance_probability(rms * PROBE_RMS_MARGIN * tail, population, tolerance):.3e}"),
-                                     "label_margin": float(f"{margin:.3e}"), "label_population": n_margins})
+                                     "exceedance_probability": float(f"{mixture_exceedance(sig, population, tolerance):.3e}"),
+                                     "label_margin": float(f"{margin:.3e}"), "label_margin_per_unit_prompt_distance": float(f"{unit:.3e}"),
+                                     "label_population": n_margins})
         if shares is not None:
             self.calibration["variance_shares"] = shares
         return self.calibration
 
-    def _measure_shares(self, tiles, ref_f, depth: int) -> dict:
+    def _measure_shares(self, tiles, ref_f, depth: int, members=None) -> dict:
         """Cosine-error variance each block's attention side / MLP contributes when it alone runs single fp16 passes and everything else split
         products (so the figure is that site's own rounding error, not the re-drawn rounding of everything downstream), plus what is left of a
-        site's share under the cheaper treatments.  Variances are the isotropic ones -- |feature error|^2 / D, the mean squared cosine error over
-        random prompt directions -- which ranks the knobs independently of any prompt bank."""
+        site's share under the cheaper treatments -- per tile group (``members``: [(name, indices into ``tiles``)]).  Variances are the isotropic
+        ones -- |feature error|^2 / D, the mean squared cosine error over random prompt directions -- which ranks the knobs independently of any
+        prompt bank.  Top-level ``attn`` / ``mlp`` / ``floor`` / ``residual_*`` hold the worst group's value per entry; ``by_group`` everything."""
         split = [(_lib.ATTN_SPLIT, _lib.MLP_SPLIT)] * depth
+        if members is None:
+            members = [("all", torch.arange(tiles.shape[0], device=tiles.device))]
+        G = len(members)
 
         def iso_var():
-            f = self.encode_image(tiles)
-            return float((f - ref_f).pow(2).sum(dim=1).mean().div(f.shape[1]))
+            f = self.encode_image(tiles) if tiles.shape[0] <= 256 else torch.cat([self.encode_image(tiles[i:i + 256]) for i in range(0, tiles.shape[0], 256)])
+            e2 = (f - ref_f).pow(2).sum(dim=1).div_(f.shape[1])
+            return [float(e2[idx].mean()) for _, idx in members]
 
         def var_of(i, mode):
             p = list(split)
@@ -573,34 +717,52 @@ class KEEPModel:
             self.set_plan(p)
             return iso_var()
 
+        def minus_floor(v):
+            return [max(v[g] - floor[g], 0.0) for g in range(G)]
+
+        def ratio(v, base):
+            return [min(v[g] / base[g], 1.0) if base[g] > 0 else 0.0 for g in range(G)]
+
         self.set_plan(split)
         floor = iso_var()
-        attn = [max(var_of(i, (_lib.ATTN_PLAIN, _lib.MLP_SPLIT)) - floor, 0.0) for i in range(depth)]
-        mlp = [max(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_PLAIN)) - floor, 0.0) for i in range(depth)]
-        res_m, res_a = dict(MLP_RESIDUAL), dict(ATTN_RESIDUAL)
+        attn = [minus_floor(var_of(i, (_lib.ATTN_PLAIN, _lib.MLP_SPLIT))) for i in range(depth)]          # [depth][G]
+        mlp = [minus_floor(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_PLAIN))) for i in range(depth)]
+        res_m = {k: [v] * G for k, v in MLP_RESIDUAL.items()}
+        res_a = {k: [v] * G for k, v in ATTN_RESIDUAL.items()}
         # what the CLS-rows-only treatment leaves differs from block to block (most in the first, where every row's error is amplified by all the
-        # attention layers that follow): measured for every block
-        cls_left = [min(max(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_CLS)) - floor, 0.0) / mlp[i], 1.0) if mlp[i] > 0 else 0.0 for i in range(depth)]
+        # attention layers that follow) and from group to group (on correlated tiles the other rows carry the SAME error): measured for every block
+        cls_left = [ratio(minus_floor(var_of(i, (_lib.ATTN_SPLIT, _lib.MLP_CLS))), mlp[i]) for i in range(depth)]
         for mode in (_lib.MLP_COMP, _lib.MLP_COMP_W):
-            fr = [max(var_of(i, (_lib.ATTN_SPLIT, mode)) - floor, 0.0) / mlp[i] for i in sorted({0, depth // 2}) if mlp[i] > 0]
-            if fr:
-                res_m[mode] = min(sum(fr) / len(fr), 1.0)
+            fr = [ratio(minus_floor(var_of(i, (_lib.ATTN_SPLIT, mode))), mlp[i]) for i in sorted({0, depth // 2})]
+            res_m[mode] = [sum(f[g] for f in fr) / len(fr) for g in range(G)]
         for mode in (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_COMPQKV):
-            if attn[0] > 0:
-                res_a[mode] = min(max(var_of(0, (mode, _lib.MLP_SPLIT)) - floor, 0.0) / attn[0], 1.0)
-        attn, mlp, floor = [float(f"{v:.3e}") for v in attn], [float(f"{v:.3e}") for v in mlp], float(f"{floor:.3e}")
-        res_m[_lib.MLP_CLS] = [float(f"{v:.4f}") for v in cls_left]
-        return {"attn": attn, "mlp": mlp, "floor": floor, "residual_mlp": {int(k): (v if isinstance(v, list) else float(f"{v:.4f}")) for k, v in res_m.items()},
-                "residual_attn": {int(k): float(f"{v:.4f}") for k, v in res_a.items()}, "probe_tiles": int(tiles.shape[0])}
+            fr = [ratio(minus_floor(var_of(i, (mode, _lib.MLP_SPLIT))), attn[i]) for i in sorted({0, depth // 2})]
+            res_a[mode] = [max(f[g] for f in fr) for g in range(G)]
+        r3 = lambda v: float(f"{v:.3e}")
+        r4 = lambda v: float(f"{v:.4f}")
+        by_group = {}
+        for g, (name, idx) in enumerate(members):
+            rm = {int(k): r4(v[g]) for k, v in res_m.items()}
+            rm[int(_lib.MLP_CLS)] = [r4(cls_left[i][g]) for i in range(depth)]
+            by_group[name] = {"attn": [r3(attn[i][g]) for i in range(depth)], "mlp": [r3(mlp[i][g]) for i in range(depth)], "floor": r3(floor[g]),
+                              "residual_mlp": rm, "residual_attn": {int(k): r4(v[g]) for k, v in res_a.items()}, "probe_tiles": int(idx.numel())}
+        worst_m = {int(k): r4(max(v)) for k, v in res_m.items()}
+        worst_m[int(_lib.MLP_CLS)] = [r4(max(cls_left[i])) for i in range(depth)]
+        return {"attn": [r3(max(attn[i])) for i in range(depth)], "mlp": [r3(max(mlp[i])) for i in range(depth)], "floor": r3(max(floor)),
+                "residual_mlp": worst_m, "residual_attn": {int(k): r4(max(v)) for k, v in res_a.items()}, "probe_tiles": int(tiles.shape[0]),
+                "groups": [name for name, _ in members], "by_group": by_group}
 
     @staticmethod
     def _greedy_walk(shares: dict, depth: int, knobs: Mapping) -> List[Tuple[Plan, float]]:
-        """[(plan, predicted cosine-error variance)] from the all-plain plan upwards: every step takes the ONE upgrade (a block's attention side or
-        MLP to one of the allowed treatments) with the largest predicted variance reduction per millisecond (KNOB_COST_MS); the last entry has
-        every site at its best allowed treatment."""
-        res_a = {int(k): v for k, v in shares["residual_attn"].items()}
-        res_m_raw = {int(k): v for k, v in shares["residual_mlp"].items()}
-        left_m = lambda i, mode: (res_m_raw[mode][i] if isinstance(res_m_raw[mode], (list, tuple)) else res_m_raw[mode])
+        """[(plan, predicted cosine-error variance of the WORST tile group)] from the all-plain plan upwards: every step takes the ONE upgrade (a
+        block's attention side or MLP to one of the allowed treatments) that lowers the worst group's predicted variance most per millisecond
+        (KNOB_COST_MS); when no upgrade moves the worst group any more, the one with the largest summed reduction.  The last entry has every site
+        at its best allowed treatment.  ``shares`` without ``by_group`` (one group) are read from the top level."""
+        groups = list(shares["by_group"].values()) if shares.get("by_group") else [shares]
+        G = len(groups)
+        res_a = [{int(k): v for k, v in g["residual_attn"].items()} for g in groups]
+        res_m = [{int(k): v for k, v in g["residual_mlp"].items()} for g in groups]
+        left_m = lambda g, i, mode: (res_m[g][mode][i] if isinstance(res_m[g][mode], (list, tuple)) else res_m[g][mode])
         cost_a = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"], _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"],
                   _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
         cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_CLS: KNOB_COST_MS["mlp_cls"], _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"],
@@ -608,24 +770,31 @@ class KEEPModel:
         am, mm = [_lib.ATTN_PLAIN] * depth, [_lib.MLP_PLAIN] * depth
 
         def predicted():
-            return shares["floor"] + sum(shares["attn"][i] * res_a[am[i]] + shares["mlp"][i] * left_m(i, mm[i]) for i in range(depth))
+            return [groups[g]["floor"] + sum(groups[g]["attn"][i] * res_a[g][am[i]] + groups[g]["mlp"][i] * left_m(g, i, mm[i]) for i in range(depth))
+                    for g in range(G)]
 
-        walk = [(list(zip(am, mm)), predicted())]
+        cur = predicted()
+        walk = [(list(zip(am, mm)), max(cur))]
         while True:
-            best, gain = None, 0.0
+            best, gain, best_sum, gain_sum = None, 0.0, None, 0.0
+            top = max(cur)
             for i in range(depth):
-                for a in knobs.get("attn", ()):
-                    dc, dv = cost_a[a] - cost_a[am[i]], shares["attn"][i] * (res_a[am[i]] - res_a[a])
-                    if dc > 0 and dv > 0 and dv / dc > gain:
-                        best, gain = (am, i, a), dv / dc
-                for m in knobs.get("mlp", ()):
-                    dc, dv = cost_m[m] - cost_m[mm[i]], shares["mlp"][i] * (left_m(i, mm[i]) - left_m(i, m))
-                    if dc > 0 and dv > 0 and dv / dc > gain:
-                        best, gain = (mm, i, m), dv / dc
+                cands = [(am, a, cost_a[a] - cost_a[am[i]], [groups[g]["attn"][i] * (res_a[g][am[i]] - res_a[g][a]) for g in range(G)]) for a in knobs.get("attn", ())]
+                cands += [(mm, m, cost_m[m] - cost_m[mm[i]], [groups[g]["mlp"][i] * (left_m(g, i, mm[i]) - left_m(g, i, m)) for g in range(G)]) for m in knobs.get("mlp", ())]
+                for target, mode, dc, dv in cands:
+                    if dc <= 0:
+                        continue
+                    drop = top - max(cur[g] - dv[g] for g in range(G))
+                    if drop > 0 and drop / dc > gain:
+                        best, gain = (target, i, mode), drop / dc
+                    if sum(dv) > 0 and sum(dv) / dc > gain_sum:
+                        best_sum, gain_sum = (target, i, mode), sum(dv) / dc
+            best = best or best_sum
             if best is None:
                 break
             best[0][best[1]] = best[2]
-            walk.append((list(zip(am, mm)), predicted()))
+            cur = predicted()
+            walk.append((list(zip(am, mm)), max(cur)))
         return walk
 
     def get_option(self, name: str) -> float:
@@ -893,8 +1062,11 @@ class KEEPModel:
                  return_features: bool = False):
         """Tiles -> (similarity [B,P] fp32, labels [B] int32[, features [B,768]]): ``encode_image`` + ``img @ txt.T`` + row argmax
         (keep_inference.py:101-104) with labels that are the fp32 reference's.  Every tile is encoded in the model's precision; the
-        tiles whose two best prompts are closer than ``margin`` in cosine (default: the engine's ``label_margin``, 2.5e-4 = twice the
-        1e-4 tolerance + 25 %) are encoded a second time with split products (``strict``) and take their row from that.
+        tiles whose two best prompts are closer than ``margin`` in cosine are encoded a second time with split products (``strict``) and
+        take their row from that.  Default margin: what ``calibrate()`` measured -- the worst error one tile's cosine DIFFERENCE can carry at the
+        calibration's confidence = (per-unit figure ``calibration["label_margin_per_unit_prompt_distance"]``) x the largest distance |t_i - t_j|
+        between two prompts of ``text_features`` (at most 2; sqrt 2 for banks without negative cosines, which is what the engine's own
+        ``label_margin`` option assumes for C-ABI callers); an uncalibrated handle starts at 2.5e-4 = twice the 1e-4 tolerance + 25 %.
         ``self.last_rechecked`` holds how many tiles that was.  ``text_features``: ``encode_text`` output ([P,768], unit norm)."""
         self._ready()
         x = image_inputs
@@ -913,6 +1085,9 @@ class KEEPModel:
         if txt.dim() != 2 or txt.shape[1] != D:
             raise ValueError(f"text_features must be [P,{D}], got {tuple(txt.shape)}")
         B, P = x.shape[0], txt.shape[0]
+        if margin is None and getattr(self, "_label_margin_unit", None):
+            margin = self._label_margin_unit * self._bank_diameter(txt)
+        self.last_margin = float(margin) if margin is not None else (self.get_option("label_margin") if self._handle.value else None)
         sim = torch.empty((B, P), dtype=torch.float32, device=self._device)
         lab = torch.empty((B,), dtype=torch.int32, device=self._device)
         feats = torch.empty((B, D), dtype=torch.float32, device=self._device) if return_features else None
@@ -930,6 +1105,18 @@ class KEEPModel:
         out = tuple(t.to(src_dev) for t in out)
         self.check_errors(wait=True)
         return out
+
+    def _bank_diameter(self, txt: torch.Tensor) -> float:
+        """max |t_i - t_j| over the rows of a prompt bank (unit rows: sqrt(2 - 2 min cos)), on the engine's own similarity kernel; cached for the
+        last bank.  Banks too large for a P x P matrix (or a single prompt) take the bound 2."""
+        P = int(txt.shape[0])
+        if P < 2 or P > 8192:
+            return 2.0
+        key = (txt.data_ptr(), P, txt._version)
+        if getattr(self, "_bank_diam_key", None) != key:
+            cos_min = float(self.similarity(txt, txt).min())
+            self._bank_diam_key, self._bank_diam = key, math.sqrt(max(2.0 - 2.0 * cos_min, 0.0))
+        return max(self._bank_diam, 1e-3)
 
     def _ready_device(self):
         self.check_errors(wait=False)

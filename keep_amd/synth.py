@@ -10,7 +10,9 @@ parity trivially true.
 """
 from __future__ import annotations
 
-from typing import Dict
+import math
+import os
+from typing import Dict, Optional
 
 import torch
 
@@ -221,3 +223,165 @@ def synthetic_rcc_prompts(prompt_sets: int = 48, seed: int = 3) -> Dict[str, dic
     templates = ["an H&E image of CLASSNAME.", "a histopathology slide showing CLASSNAME.", "tissue with features consistent with CLASSNAME."]
     rnd = random.Random(seed)
     return {str(i): {"classnames": {k: rnd.choice(v) for k, v in names.items()}, "templates": rnd.choice(templates)} for i in range(prompt_sets)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Structured tile families: pixels that look like what the reference transform (keep_inference.py:88-93; the WSI scripts' tiles,
+# zeroshot_subtyping_WSI.py:47-52) hands to encode_image -- uint8 RGB tiles, spatially correlated, non-zero channel means after the
+# ImageNet normalisation, and slides full of near-constant background -- instead of the i.i.d. N(0,1) pixels of BASELINE config 2.
+# Every family is generated ON the device as uint8 [n,224,224,3] (HWC, what encode_image_uint8 takes); a tile's pixels depend only on
+# (family, seed, global tile index // unit), like synth_tiles_device.
+# ------------------------------------------------------------------------------------------------------------------
+TILE_FAMILIES = ("he_crops", "stain_field", "background", "half", "mixed")
+_STAIN_H = (0.65, 0.70, 0.29)      # optical-density vectors of haematoxylin / eosin (Ruifrok & Johnston colour deconvolution)
+_STAIN_E = (0.07, 0.99, 0.11)
+
+
+def _octave_field(n: int, g: torch.Generator, device, beta: float = 1.0, octaves: int = 7, size: int = 224) -> torch.Tensor:
+    """[n,1,size,size] low-pass ("1/f^beta") noise, zero mean / unit variance per tile: a sum of bilinearly up-sampled white-noise grids,
+    octave o (a 2^(o+1)+1 point grid) weighted 2^(-o beta)."""
+    import torch.nn.functional as F
+    out = torch.zeros(n, 1, size, size, device=device)
+    for o in range(octaves):
+        k = 2 ** (o + 1) + 1
+        grid = torch.randn(n, 1, k, k, device=device, generator=g)
+        out += F.interpolate(grid, size=(size, size), mode="bilinear", align_corners=True) * (2.0 ** (-o * beta))
+    out -= out.mean(dim=(2, 3), keepdim=True)
+    return out / out.std(dim=(2, 3), keepdim=True).clamp_min(1e-6)
+
+
+def _stain_field_tiles(n: int, g: torch.Generator, device) -> torch.Tensor:
+    """H & E by Beer-Lambert: RGB = 255 * 10^-(c_H v_H + c_E v_E) with two correlated low-pass concentration fields (nuclei = peaks of a
+    sharper field), per-tile staining strength, sensor noise.  float [n,3,224,224] in 0..255 (not yet rounded)."""
+    base, fine = _octave_field(n, g, device, beta=1.2), _octave_field(n, g, device, beta=0.4)
+    strength = 0.6 + 0.8 * torch.rand(n, 1, 1, 1, device=device, generator=g)
+    c_e = (0.35 + 0.25 * base).clamp_min(0.0) * strength                                  # eosin: stroma / cytoplasm, smooth
+    c_h = (0.9 * torch.sigmoid(4.0 * (0.6 * fine + 0.4 * base) - 3.0)) * strength         # haematoxylin: sparse dark nuclei
+    vh = torch.tensor(_STAIN_H, device=device).view(1, 3, 1, 1)
+    ve = torch.tensor(_STAIN_E, device=device).view(1, 3, 1, 1)
+    rgb = 255.0 * torch.pow(10.0, -(c_h * vh * 1.4 + c_e * ve * 0.6))
+    return rgb + 2.0 * torch.randn(n, 3, 224, 224, device=device, generator=g)
+
+
+def _background_tiles(n: int, g: torch.Generator, device) -> torch.Tensor:
+    """What most of a slide is: glass.  45 % near-white with sensor noise, 25 % exactly 255 (saturated), 15 % light grey with a tint,
+    10 % black (outside the scanned area / pen), 5 % a flat mid-grey.  float [n,3,224,224] in 0..255."""
+    kind = torch.rand(n, device=device, generator=g)
+    level = torch.where(kind < 0.45, 244.0 + 8.0 * torch.rand(n, device=device, generator=g),
+                        torch.where(kind < 0.70, torch.full((n,), 255.0, device=device),
+                                    torch.where(kind < 0.85, 215.0 + 25.0 * torch.rand(n, device=device, generator=g),
+                                                torch.where(kind < 0.95, torch.zeros(n, device=device), torch.full((n,), 128.0, device=device)))))
+    tint = torch.where(((kind >= 0.70) & (kind < 0.85))[:, None], 6.0 * (torch.rand(n, 3, device=device, generator=g) - 0.5), torch.zeros(n, 3, device=device))
+    sigma = torch.where((kind >= 0.45) & (kind < 0.70), 0.0, 1.5)
+    noise = torch.randn(n, 3, 224, 224, device=device, generator=g) * sigma.view(n, 1, 1, 1)
+    return (level.view(n, 1, 1, 1) + tint.view(n, 3, 1, 1)).expand(n, 3, 224, 224) + noise
+
+
+def _he_crop_tiles(n: int, g: torch.Generator, device, base_image: torch.Tensor) -> torch.Tensor:
+    """Random resized crops (scale 0.45-1 of the short side), flips, quarter turns and a mild colour jitter of ONE real H & E image
+    (``base_image``: uint8 [H,W,3], e.g. the reference's quick_start/example.tif).  float [n,3,224,224] in 0..255."""
+    import torch.nn.functional as F
+    img = base_image.to(device=device, dtype=torch.float32).permute(2, 0, 1)[None]
+    H, W = img.shape[2], img.shape[3]
+    u = torch.rand(n, 8, device=device, generator=g)
+    side = (0.45 + 0.55 * u[:, 0]) * min(H, W)                                           # crop side in pixels
+    cx = side / 2 + u[:, 1] * (W - side)
+    cy = side / 2 + u[:, 2] * (H - side)
+    quarter = torch.floor(u[:, 3] * 4.0) * (math.pi / 2)
+    flip = torch.where(u[:, 4] < 0.5, -1.0, 1.0)
+    cos, sin = torch.cos(quarter), torch.sin(quarter)
+    sx, sy = side / W, side / H                                                           # normalised half-extents
+    theta = torch.stack([torch.stack([sx * cos * flip, -sx * sin, 2 * cx / W - 1], 1),
+                         torch.stack([sy * sin * flip, sy * cos, 2 * cy / H - 1], 1)], 1)
+    grid = F.affine_grid(theta, (n, 3, 224, 224), align_corners=False)
+    crops = F.grid_sample(img.expand(n, -1, -1, -1), grid, mode="bilinear", padding_mode="border", align_corners=False)
+    gain = 0.9 + 0.2 * torch.rand(n, 3, 1, 1, device=device, generator=g)
+    offset = 16.0 * (torch.rand(n, 3, 1, 1, device=device, generator=g) - 0.5)
+    return (crops - 128.0) * gain + 128.0 + offset
+
+
+def _default_base_image() -> torch.Tensor:
+    """The one real tile this repository holds: the reference's quick-start image, kept as a data fixture (tests/golden/example.tif)."""
+    import numpy as np
+    from PIL import Image
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "example.tif")
+    return torch.from_numpy(np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8).copy())
+
+
+def synth_tile_family(family: str, a: int, b: int, device, seed: int = 7000, unit: int = 256,
+                      base_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Tiles [a, b) of an endless synthetic slide of one of ``TILE_FAMILIES``, uint8 [b-a,224,224,3] on ``device``:
+
+      he_crops     random resized crops / flips / quarter turns / colour jitter of a real H & E image (``base_image``, default example.tif)
+      stain_field  Beer-Lambert H & E from two low-pass (1/f) stain-concentration fields: correlated pixels, pink-purple channel means
+      background   glass: near-white + noise, saturated 255, tinted light grey, black, flat grey -- near-constant tiles
+      half         one side of a random straight edge is background, the other stain_field
+      mixed        tile i is of family (he_crops, stain_field, background, half)[i % 4]: a slide
+
+    ``normalise_u8`` turns them into the float tiles ``encode_image`` takes (ToTensor + Normalize, keep_inference.py:91-92)."""
+    if family not in TILE_FAMILIES:
+        raise ValueError(f"family {family!r}: one of {TILE_FAMILIES}")
+    if b <= a:
+        return torch.empty((0, 224, 224, 3), device=device, dtype=torch.uint8)
+    if family == "he_crops" or family == "mixed":
+        base_image = _default_base_image() if base_image is None else base_image
+    fid = TILE_FAMILIES.index(family)
+    parts = []
+    for u in range(a // unit, (b - 1) // unit + 1):
+        g = torch.Generator(device=device).manual_seed(seed + 1_000_003 * fid + u)
+        if family == "he_crops":
+            x = _he_crop_tiles(unit, g, device, base_image)
+        elif family == "stain_field":
+            x = _stain_field_tiles(unit, g, device)
+        elif family == "background":
+            x = _background_tiles(unit, g, device)
+        elif family == "half":
+            tex, bg = _stain_field_tiles(unit, g, device), _background_tiles(unit, g, device)
+            ang = 2 * math.pi * torch.rand(unit, 1, 1, device=device, generator=g)
+            off = 60.0 * (torch.rand(unit, 1, 1, device=device, generator=g) - 0.5)
+            yy, xx = torch.meshgrid(torch.arange(224.0, device=device) - 111.5, torch.arange(224.0, device=device) - 111.5, indexing="ij")
+            side = (xx[None] * torch.cos(ang) + yy[None] * torch.sin(ang) + off) > 0
+            x = torch.where(side[:, None], tex, bg)
+        else:
+            quarter = unit // 4
+            x = torch.cat([_he_crop_tiles(quarter, g, device, base_image), _stain_field_tiles(quarter, g, device),
+                           _background_tiles(quarter, g, device), _stain_field_tiles(unit - 3 * quarter, g, device)], 0)
+            bgm = _background_tiles(unit - 3 * quarter, g, device)
+            edge = (torch.arange(224.0, device=device) - 111.5)[None, None, None, :] > 40.0 * (torch.rand(unit - 3 * quarter, 1, 1, 1, device=device, generator=g) - 0.5)
+            x[3 * quarter:] = torch.where(edge, x[3 * quarter:], bgm)
+            # interleave: tile i of the unit is of family i % 4
+            order = torch.arange(unit, device=device)
+            src = (order % 4) * quarter + order // 4
+            x = x[src.clamp_max(unit - 1)]
+        x = x.clamp_(0.0, 255.0).round_().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        parts.append(x[max(a - u * unit, 0): min(b - u * unit, unit)])
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+
+def normalise_u8(tiles_u8: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """ToTensor + Normalize(ImageNet mean / std) of the reference transform (keep_inference.py:91-92) on uint8 [n,224,224,3] -> [n,3,224,224]."""
+    from .preprocess import IMAGENET_MEAN, IMAGENET_STD
+    x = tiles_u8.permute(0, 3, 1, 2).to(torch.float32) / 255.0
+    mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    return ((x - mean) / std).to(dtype)
+
+
+PROBE_FAMILIES = ("gaussian", "stain_field", "background", "half")
+
+
+def calibration_probe(n_per_family: int, device, seed: int = 20250929, families=PROBE_FAMILIES, dtype=torch.bfloat16):
+    """The probe ``KEEPModel.calibrate`` / ``calibrate_bias`` use when the caller passes no tiles of their own: ``n_per_family`` tiles of each of
+    ``families`` -- i.i.d. N(0,1) pixels (BASELINE config 2) AND the structured families above (none needs a file; ``he_crops``, the real-image
+    one, stays out on purpose: it is the held-out family the tests evaluate on).  -> (tiles [n,3,224,224] ``dtype``, normalised as the reference
+    transform does; group index of every tile, int64 [n] on the CPU; the family names)."""
+    parts, groups = [], []
+    for gi, fam in enumerate(families):
+        if fam == "gaussian":
+            g = torch.Generator(device=device).manual_seed(seed)
+            x = torch.randn(n_per_family, 3, 224, 224, device=device, generator=g, dtype=torch.float32).to(dtype)
+        else:
+            x = normalise_u8(synth_tile_family(fam, 0, n_per_family, device, seed=seed % 1_000_003), dtype)
+        parts.append(x)
+        groups.append(torch.full((n_per_family,), gi, dtype=torch.int64))
+    return torch.cat(parts, 0), torch.cat(groups, 0), tuple(families)

@@ -599,6 +599,10 @@ def test_config3_fixture_first_chunk(golden_dir):
             assert 0 < m.last_rechecked < chunk // 4
             lm = m.get_option("label_margin")                       # set by calibrate(): sqrt 2 x the predicted worst cosine error (<= 1.42e-4), not a fixed 2.5e-4
             assert 5e-5 < lm <= 2 ** 0.5 * COS_TOL * 1.001 and lm == pytest.approx(m.calibration["label_margin"], rel=1e-3)
+            # classify scales the calibrated per-unit margin by THIS bank's largest prompt distance (<= 2; sqrt 2 is the engine's own default)
+            diam = float((2.0 - 2.0 * (txt @ txt.t()).min()).clamp_min(0).sqrt())
+            assert m.last_margin == pytest.approx(m.calibration["label_margin_per_unit_prompt_distance"] * diam, rel=1e-3) and m.last_margin <= lm * 2 ** 0.5 * 1.001
+            lm = m.last_margin
             flagged = (csim.topk(2, dim=1).values.diff(dim=1).abs().squeeze(1) < 0.9 * lm).cpu()      # rows that were looked at again carry strict-grade cosines
             assert (dc[flagged].max() < 5e-6) if flagged.any() else True
         else:
@@ -801,7 +805,8 @@ def test_calibrate_walks_its_candidates_and_reports(small, budget):
             assert c["exceedance_probability"] <= 1.0 - c["confidence"] + 1e-9
             from keep_amd.model import max_sigmas_quantile
             z_ratio = max_sigmas_quantile(c["label_population"], c["confidence"]) / max_sigmas_quantile(c["population"], c["confidence"])
-            assert c["label_margin"] == pytest.approx(2 ** 0.5 * c["predicted_max_abs_dcos"] * z_ratio, rel=1e-2) and z_ratio <= 1.0
+            # one margin per tile: the quantile over the label population of the same per-tile error mixture (equal sigmas: exactly the ratio of the two quantiles)
+            assert 0.9 * z_ratio <= c["label_margin"] / (2 ** 0.5 * c["predicted_max_abs_dcos"]) <= 1.0 + 1e-6 and z_ratio <= 1.0
     if hi["precision"] == "comp":
         assert m.get_option("label_margin") == pytest.approx(hi["label_margin"], rel=1e-3)         # the last calibration set the engine's second-look threshold
     # strict_blocks set by the caller survives a calibration (it used to be reset to 0)
@@ -893,7 +898,7 @@ def test_mean_input_bias_compensation():
     m.set_precision("comp")
     m.set_plan([(0, 0)] * 24)
     off = m.similarity(m.encode_image(x), bank)
-    m.calibrate_bias()
+    m.calibrate_bias(probe="gaussian")                 # the probe of the distribution it is evaluated on (off that distribution: tests/test_tile_families.py)
     assert m.get_option("bias_ready") == 1 and m.get_option("bias_correction") == 1
     on = m.similarity(m.encode_image(x), bank)
     rms = lambda d: float(d.pow(2).mean().sqrt())
@@ -904,7 +909,7 @@ def test_mean_input_bias_compensation():
     assert torch.equal(m.similarity(m.encode_image(x), bank), off)                 # switched off: the checkpoint's biases, bit for bit
     m.set_option("bias_correction", 1)
     assert torch.equal(m.similarity(m.encode_image(x), bank), on)                  # deterministic
-    m.calibrate_bias(); assert torch.equal(m.similarity(m.encode_image(x), bank), on)      # and reproducible: no atomics in the averages
+    m.calibrate_bias(probe="gaussian"); assert torch.equal(m.similarity(m.encode_image(x), bank), on)      # and reproducible: no atomics in the averages
     # split / compensated launches compute the W_lo term themselves: the all-split plan does not change
     m.set_plan([(1, 1)] * 24)
     sp_on = m.encode_image(x[:32])
