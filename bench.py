@@ -3,7 +3,8 @@
 (BASELINE.json configs[1]: batch 256 synthetic bf16 tiles per GPU, random-init weights).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                      (starts the N ranks itself: re-executes under torch.distributed.run, one rank per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...        (the same, launched from outside)
 
 One step = KEEPModel.encode_image on one batch of 256 device-resident tiles per rank (+ the RCCL
 all-gather of the [256,768] embeddings when N > 1: the slide-level pooling exchange of config 4).
@@ -430,6 +431,82 @@ def config5(model, dev, n: int = 100_000):
             "within_fp16_rounding_of_oracle": bool(err <= half_ulp + 1e-6)}
 
 
+def slide_leg(model, dev, n: int, rank: int, world: int, distinct: int = 264, K: int = 1782, topn: int = 50):
+    """BASELINE configs 4 and 5 in their stated MULTI-GPU layout: the synthetic slide's `n` tiles in contiguous shards of ceil(n / world)
+    per rank (12 500 at n = 100 000, world = 8), encoded in batches of 256 with the RCCL all-gather of batch j's [256, 768] embeddings issued under
+    the encode of batch j + 1 (keep_amd.distributed.encode_tiles_sharded); then ON EVERY RANK, from the gathered [n, 768] matrix: prompt screening
+    over a K x 4 classifier bank, the ensemble, the slide label (subtyping on a 256-px grid) and the tumour ratio; and config 5's fp16 probability
+    map of the rank's own shard.  Every rank must end with the same embedding matrix (checksum), the same label and the same ratio."""
+    import torch.distributed as dist
+    from keep_amd import wsi
+    from keep_amd.distributed import encode_tiles_sharded, shard_bounds
+    from keep_amd.synth import synth_tiles_device
+    toksD = synth_prompts(distinct, 256, seed=5)
+    txtD = torch.cat([model.encode_text({k: v[i:i + 64].to(dev) for k, v in toksD.items()}) for i in range(0, distinct, 64)])
+    bank4 = rcc_shaped_bank(txtD, K)
+    bank2 = [c[:, :2].contiguous() for c in bank4]
+    load = lambda a, b: synth_tiles_device(a, b, dev, torch.bfloat16, seed=C4_SEEDS[0])
+    fence = lambda: (dist.barrier() if dist.is_initialized() else None, torch.cuda.synchronize(dev))
+    encode_tiles_sharded(model.encode_image, min(n, 512 * world), load, batch=256)          # warm-up (workspace, communicator)
+    fence()
+    t0 = time.perf_counter()
+    feats = encode_tiles_sharded(model.encode_image, n, load, batch=256)
+    fence()
+    t_enc = time.perf_counter() - t0
+    side = int(n ** 0.5) + 1
+    idx = torch.arange(n)
+    coords = torch.stack([(idx % side) * 256, (idx // side) * 256], 1).numpy()
+    t1 = time.perf_counter()
+    ens4 = wsi.zero_shot_prompt_select(bank4, feats, topn, dev, model=model)
+    label = int(wsi.zero_shot_subtyping(ens4, feats, coords, 256, True, model=model))
+    ens2 = wsi.zero_shot_prompt_select(bank2, feats, topn, dev, model=model)
+    ratio = float(wsi.zero_shot_detection(ens2, feats, coords, 256, False, model=model))
+    lo, hi = shard_bounds(n, rank, world)
+    pmap = model.similarity(feats[lo:hi], ens2.t().contiguous(), scale=10.0, mode="softmax_f16")      # config 5: this rank's share of the dense map
+    torch.cuda.synchronize(dev)
+    t_slide = time.perf_counter() - t1
+    row = torch.tensor([float(feats.double().sum()), float(feats.double().pow(2).sum()), float(label), ratio, float(pmap.float().sum()), t_enc, t_slide],
+                       dtype=torch.float64, device=dev)
+    rows = [torch.empty_like(row) for _ in range(world)]
+    if dist.is_initialized():
+        dist.all_gather(rows, row)
+    else:
+        rows = [row]
+    got = [r.tolist() for r in rows]
+    same = all(g[:4] == got[0][:4] for g in got)
+    return {"workload": f"configs 4 + 5 in the multi-GPU layout: {n} synthetic tiles in contiguous shards of <= {-(-n // world)} per rank x {world} rank(s), RCCL "
+                        f"all-gather of every 256-tile batch's embeddings under the next batch's encode, then on every rank: screening over {K} x 4 prompts, "
+                        "ensemble, slide label, tumour ratio; fp16 probability map of the rank's shard",
+            "tiles": n, "ranks": world, "tiles_per_rank": hi - lo, "encode_and_gather_seconds_max_over_ranks": round(max(g[5] for g in got), 3),
+            "tiles_per_s_whole_slide": round(n / max(g[5] for g in got), 1), "slide_level_seconds_max_over_ranks": round(max(g[6] for g in got), 3),
+            "slide_label": label, "tumour_ratio": round(ratio, 5), "prob_map_rows_this_rank": int(pmap.shape[0]),
+            "every_rank_same_embeddings_label_ratio": bool(same), "embedding_checksums": [g[0] for g in got]}
+
+
+def spawn_ranks(n: int) -> int:
+    """Re-run this command under `torch.distributed.run` with one rank per GPU of this node (loopback rendezvous on a free port) and return its
+    exit code; rank 0 of the children prints the JSON line on this process's stdout.  Fails loudly when the node has fewer GPUs than asked for."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node: not launching (a line with n_gpus != the ranks that ran is never printed)",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.pop("KEEP_BENCH_FORCE_SPAWN", None)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    if n == 1:
+        env["KEEP_BENCH_FORCE_DIST"] = "1"           # the forced one-rank spawn (tests) goes through the RCCL path too
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"launching {n} rank(s): {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,18 +526,30 @@ def main():
     ap.add_argument("--c4-tiles", type=int, default=100_000)
     ap.add_argument("--c4-budget-seconds", type=float, default=150.0, help="no further config-4 slide is started once the run is this old (the first one always runs)")
     ap.add_argument("--c4-seeds", type=int, default=len(C4_SEEDS), help="number of 100 000-tile synthetic slides of the config-4 leg (about 50 s each)")
+    ap.add_argument("--slide", action="store_true", help="also run configs 4 + 5 in their multi-GPU layout (tiles sharded over the ranks, RCCL all-gather of the embeddings, "
+                                                         "slide label / tumour ratio on every rank): the `slide` key of the line")
+    ap.add_argument("--slide-tiles", type=int, default=100_000)
     ap.add_argument("--budget", default=None, choices=["ladder", "measured"], help="re-run KEEPModel.calibrate with this budget after loading")
     ap.add_argument("--plan", default=None, help="run this per-block plan instead of the calibrated one: the 'attn:<digits> mlp:<digits>' string a bench line "
                                                  "reports (profiling runs: KEEP_CALIBRATE=0 keeps the calibration's kernels out of the trace)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: keep_amd has no CPU execution path")
+    launched = "WORLD_SIZE" in os.environ            # under torch.distributed.run (the documented N > 1 launch) the ranks already exist
+    if not launched and (args.gpus > 1 or os.environ.get("KEEP_BENCH_FORCE_SPAWN") == "1"):
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU over RCCL), never report a line whose n_gpus
+        # differs from the ranks that ran
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: keep_amd has no CPU execution path")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus must be the number of ranks that ran")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -555,6 +644,14 @@ def main():
         exchange_cost = {"ms_per_step_with_exchange": round(elapsed / args.steps * 1e3, 3), "ms_per_step_encode_only": round(el0 / args.steps * 1e3, 3),
                          "exposed_ms_per_step": round((elapsed - el0) / args.steps * 1e3, 3),
                          "bytes_gathered_per_step": world * B * shape.projection_dim * 4}
+
+    slide = None
+    if args.slide:
+        log(f"slide leg: {args.slide_tiles} tiles over {world} rank(s) ...")
+        slide = slide_leg(model, dev, args.slide_tiles, rank, world)
+        if not slide["every_rank_same_embeddings_label_ratio"]:
+            raise SystemExit(f"slide leg: the ranks disagree on the gathered embeddings / label / ratio: {slide}")
+        model.reserve(tiles=args.batch)
 
     # effective shader clock under this load: a one-wave probe (shader cycles against the 100 MHz reference counter) on a side stream, right after
     # the timed region (the queue is still full of encodes: the probe lands between them) and again during the sustained region
@@ -720,6 +817,8 @@ def main():
         if per_rank is not None:
             line["per_rank_tiles_per_s"] = per_rank
             line["exchange"] = exchange_cost
+        if slide is not None:
+            line["slide"] = slide
         if breakdown is not None:
             line["breakdown_ms_per_step_single_stream"] = breakdown
         if world == 1 and not args.no_cpu_baseline:

@@ -178,3 +178,17 @@ def test_rccl_env_defaults(monkeypatch):
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
     rccl_env()
     assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"          # an operator's setting wins
+
+
+def test_bench_without_a_gpu_prints_no_line():
+    """`python bench.py --gpus 2` on a box without GPUs: non-zero exit, a reason on stderr, no JSON line on stdout (the product has no CPU path and a
+    mislabelled line is worse than none)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("this is the no-GPU statement")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "MI355X" in r.stderr
+    assert not any(line.lstrip().startswith("{") for line in r.stdout.splitlines())

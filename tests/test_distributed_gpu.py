@@ -132,3 +132,32 @@ def test_two_ranks_over_rccl_match_the_single_process_result(n_tiles):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert [r[0] for r in res] == [0, 1] and all(r[1] and r[2] and r[3] == 2 for r in res), res
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` as the driver invokes it (no torchrun around it): with fewer than N GPUs visible it must exit non-zero with a clear
+    message and print NO JSON line -- never a 1-GPU figure labelled as N."""
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert f"--gpus {n}" in r.stderr and "visible" in r.stderr
+    assert not any(line.lstrip().startswith("{") for line in r.stdout.splitlines())
+
+
+def test_bench_starts_its_own_ranks():
+    """The self-spawn path on the one GPU the test box has (KEEP_BENCH_FORCE_SPAWN=1 makes `--gpus 1` take it): bench.py re-executes under
+    torch.distributed.run, the rank initialises RCCL, runs the step loop with the all-gather and the configs-4/5 multi-GPU slide leg, and the parent's
+    stdout ends with ONE JSON line whose n_gpus is the number of ranks RCCL saw."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["KEEP_BENCH_FORCE_SPAWN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-breakdown",
+                        "--no-configs", "--no-sustained", "--slide", "--slide-tiles", "1500"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["rccl_ranks_seen"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["exchange"]
+    sl = line["slide"]
+    assert sl["tiles"] == 1500 and sl["ranks"] == 1 and sl["tiles_per_rank"] == 1500 and sl["prob_map_rows_this_rank"] == 1500
+    assert sl["every_rank_same_embeddings_label_ratio"] and 0 <= sl["slide_label"] < 4 and 0.0 <= sl["tumour_ratio"] <= 1.0
