@@ -253,8 +253,8 @@ def config4(model, dev, n: int = 100_000, distinct: int = 264, K: int = 1782, to
         out = torch.empty(n, 768, device=dev)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for a in range(0, n, 256):
-            b = min(a + 256, n)
+        for a in range(0, n, 512):             # 512 tiles per call: two lanes of 256 (+1.7 % over 256-tile calls, profiles/r05_step_boundary_bubble.txt)
+            b = min(a + 512, n)
             out[a:b] = model.encode_image(synth_tiles_device(a, b, dev, torch.bfloat16, seed=seed))
         torch.cuda.synchronize(dev)
         return out, time.perf_counter() - t0
@@ -376,8 +376,8 @@ def structured_slide_parity(model, dev, family: str = "mixed", n: int = 100_000,
         out = torch.empty(n, 768, device=dev)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for a in range(0, n, 256):
-            b = min(a + 256, n)
+        for a in range(0, n, 512):
+            b = min(a + 512, n)
             out[a:b] = model.encode_image_uint8(synth_tile_family(family, a, b, dev, seed=seed))
         torch.cuda.synchronize(dev)
         return out, time.perf_counter() - t0
@@ -433,7 +433,7 @@ def config5(model, dev, n: int = 100_000):
 
 def slide_leg(model, dev, n: int, rank: int, world: int, distinct: int = 264, K: int = 1782, topn: int = 50):
     """BASELINE configs 4 and 5 in their stated MULTI-GPU layout: the synthetic slide's `n` tiles in contiguous shards of ceil(n / world)
-    per rank (12 500 at n = 100 000, world = 8), encoded in batches of 256 with the RCCL all-gather of batch j's [256, 768] embeddings issued under
+    per rank (12 500 at n = 100 000, world = 8), encoded in batches of 512 with the RCCL all-gather of batch j's [512, 768] embeddings issued under
     the encode of batch j + 1 (keep_amd.distributed.encode_tiles_sharded); then ON EVERY RANK, from the gathered [n, 768] matrix: prompt screening
     over a K x 4 classifier bank, the ensemble, the slide label (subtyping on a 256-px grid) and the tumour ratio; and config 5's fp16 probability
     map of the rank's own shard.  Every rank must end with the same embedding matrix (checksum), the same label and the same ratio."""
@@ -447,10 +447,10 @@ def slide_leg(model, dev, n: int, rank: int, world: int, distinct: int = 264, K:
     bank2 = [c[:, :2].contiguous() for c in bank4]
     load = lambda a, b: synth_tiles_device(a, b, dev, torch.bfloat16, seed=C4_SEEDS[0])
     fence = lambda: (dist.barrier() if dist.is_initialized() else None, torch.cuda.synchronize(dev))
-    encode_tiles_sharded(model.encode_image, min(n, 512 * world), load, batch=256)          # warm-up (workspace, communicator)
+    encode_tiles_sharded(model.encode_image, min(n, 1024 * world), load, batch=512)         # warm-up (workspace, communicator)
     fence()
     t0 = time.perf_counter()
-    feats = encode_tiles_sharded(model.encode_image, n, load, batch=256)
+    feats = encode_tiles_sharded(model.encode_image, n, load, batch=512)                    # 512 tiles per call = two lanes of 256; the all-gather of call j under call j + 1
     fence()
     t_enc = time.perf_counter() - t0
     side = int(n ** 0.5) + 1
@@ -475,7 +475,7 @@ def slide_leg(model, dev, n: int, rank: int, world: int, distinct: int = 264, K:
     got = [r.tolist() for r in rows]
     same = all(g[:4] == got[0][:4] for g in got)
     return {"workload": f"configs 4 + 5 in the multi-GPU layout: {n} synthetic tiles in contiguous shards of <= {-(-n // world)} per rank x {world} rank(s), RCCL "
-                        f"all-gather of every 256-tile batch's embeddings under the next batch's encode, then on every rank: screening over {K} x 4 prompts, "
+                        f"all-gather of every 512-tile batch's embeddings under the next batch's encode, then on every rank: screening over {K} x 4 prompts, "
                         "ensemble, slide label, tumour ratio; fp16 probability map of the rank's shard",
             "tiles": n, "ranks": world, "tiles_per_rank": hi - lo, "encode_and_gather_seconds_max_over_ranks": round(max(g[5] for g in got), 3),
             "tiles_per_s_whole_slide": round(n / max(g[5] for g in got), 1), "slide_level_seconds_max_over_ranks": round(max(g[6] for g in got), 3),

@@ -71,7 +71,11 @@ enum {
     KEEP_ATTN_PLAIN = 0,          /* qkv, q/k/v storage, attention, proj: single fp16 passes                                       */
     KEEP_ATTN_SPLIT = 1,          /* all four as split products (three fp16 passes; q/k/v and the attention output stored hi + lo)  */
     KEEP_ATTN_SPLIT_COMPQKV = 2,  /* the same with the qkv GEMM as a compensated product (fp16 pass + MX-fp4 correction terms)      */
-    KEEP_ATTN_COMPQKV = 3         /* only the qkv GEMM compensated; attention and proj plain                                       */
+    KEEP_ATTN_COMPQKV = 3,        /* only the qkv GEMM compensated; attention and proj plain                                       */
+    KEEP_ATTN_PROJ_CLS = 4        /* single fp16 passes for every row; the attention output of the CLS row of every tile is ALSO kept */
+                                  /* hi + lo from the fp32 accumulators and its proj runs again as a split product (B rows): on      */
+                                  /* spatially correlated tiles the proj GEMM carries ~70 % of the attention side's rounding error   */
+                                  /* and the CLS row's own share of it is what reaches the pooled feature (round 6)                  */
 };
 enum {
     KEEP_MLP_PLAIN = 0,           /* fc1 / fc2: single fp16 passes                                                                  */

@@ -341,6 +341,11 @@ void attention_kernel(AttnParams p) {
                 const unsigned oo = (unsigned)(mrow >> 8) * o_sa + (unsigned)(mrow & 255) * o_sb + o_g0 + (unsigned)(dt >> 1) * o_ga + (unsigned)(dt & 1) * 16u;
                 *reinterpret_cast<f16x4*>(p.out_hi + oo) = oh;
                 if (SPLIT) *reinterpret_cast<f16x4*>(p.out_lo + oo) = ol;
+                if (!SPLIT && p.cls_hi && q == 0) {           // the CLS row once more, hi + lo, into row b of the compact operand (same layout constants)
+                    const unsigned oc = (unsigned)(b >> 8) * o_sa + (unsigned)(b & 255) * o_sb + o_g0 + (unsigned)(dt >> 1) * o_ga + (unsigned)(dt & 1) * 16u;
+                    *reinterpret_cast<f16x4*>(p.cls_hi + oc) = oh;
+                    *reinterpret_cast<f16x4*>(p.cls_lo + oc) = ol;
+                }
             }
         }
     }
@@ -518,6 +523,17 @@ void attention_pers_kernel(AttnParams p) {
                     const unsigned oo = (unsigned)(mrow >> 8) * o_sa + (unsigned)(mrow & 255) * o_sb + o_g0 + (unsigned)(dt >> 1) * o_ga + (unsigned)(dt & 1) * 16u;
                     *reinterpret_cast<f16x4*>(p.out_hi + oo) = oh;
                 }
+                if (p.cls_hi && qrow == 0) {                  // KEEP_ATTN_PROJ_CLS: the CLS row once more, hi + lo, into row b of the compact operand
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        f16x4 oh, ol;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { f16 hh, ll; split_f16(o[dt][r] * inv, hh, ll); oh[r] = hh; ol[r] = ll; }
+                        const unsigned oc = (unsigned)(b >> 8) * o_sa + (unsigned)(b & 255) * o_sb + o_g0 + (unsigned)(dt >> 1) * o_ga + (unsigned)(dt & 1) * 16u;
+                        *reinterpret_cast<f16x4*>(p.cls_hi + oc) = oh;
+                        *reinterpret_cast<f16x4*>(p.cls_lo + oc) = ol;
+                    }
+                }
             }
         }
         if (!more) break;
@@ -562,6 +578,7 @@ int launch_attention(const AttnParams& p_in, hipStream_t s) {
     const int nt = (p.ntok + 15) / 16;
     if (p.ntok < 1 || p.batch < 1) return -1;
     if (p.q_hi && (p.q_rows != 1 || p.split)) return -1;          // the compact query buffer holds one row per image, single-pass only
+    if ((p.cls_hi != nullptr) != (p.cls_lo != nullptr) || (p.cls_hi && (p.split || p.mask))) return -1;      // CLS-row hi + lo copy: both planes, single-pass image tower only
     // 32-bit lane offsets inside the kernel: qkv rows of one (batch) slice and the whole output plane (padded to 256 rows) stay below 2^31 elements
     if ((int64_t)p.ntok * 3 * p.heads * HD >= (1ll << 31) || ((int64_t)p.batch * p.ntok + 255) / 256 * 256 * p.heads * HD >= (1ll << 31)) return -1;
     if (p.split) {

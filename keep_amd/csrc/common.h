@@ -69,6 +69,7 @@ static inline size_t blk_elems(int64_t M, int64_t K) { return (size_t)((M + 255)
 struct KeepTune {
     int gemm_impl = 0;           // 0 auto | 128 / 256: LDS-DMA tile width 
     int gemm_skinny_m = 320;     // calls with M <= this take the register-direct split-K kernel (0: never)
+    int skinny_wide = 1;         // 1: small-M calls with M >= 64 on the 128x128 / 64x64-per-wave kernel (two MFMAs per fragment loaded); 0: 32x128 tiles always (A/B)
     int gemm_splitk_tiles = 64;  // a 256x256 GEMM with fewer tiles than this is cut into K slices (0: never)
     int sgemv_m = 16;            // rows up to which the few-row fp32 kernel is used (0: never)
     int ln_impl = 2;             // 2 (default): LDS-transposed blk stores from 4-wave workgroups (one 56-register wave per SIMD: fits beside two waves of the other lane's
@@ -154,6 +155,9 @@ struct AttnParams {
     const f16* q_hi; int q_ld;            // q_rows == 1 only, nullable: the ONE query row of image b at q_hi + b * q_ld (head-major, like the q part of a qkv row) instead of
                                           // qkv_hi -- the last block computes Q for its CLS rows only
     int split;                            // 0/1
+    // nullable (single-pass mode only): the attention output of query row 0 (the CLS row) of image b, from the fp32 accumulators, ALSO as hi + lo
+    // planes into row b of a compact [batch][D] operand in the layout of `out_*` (KEEP_ATTN_PROJ_CLS: the CLS rows' proj runs again as a split product)
+    f16* cls_hi; f16* cls_lo;
     // split mode with 256 < ntok <= 512: the K / V planes (hi + lo) of more than 256 keys do not fit the LDS, so the keys are processed in two
     // windows of <= 256 (two launches) and merged like an online softmax.  part_ws: caller's scratch, batch * heads * ntok * ATT_PART_FLOATS floats
     // (unnormalised output row + running maximum + sum per query); launch_attention fills key0 / kcount / part_out / part_in itself.

@@ -107,7 +107,8 @@ struct keep_handle {
     int comp_qkv_from = 1 << 20; // the same for the split-attention blocks with index >= this only (block 0 keeps its three-pass qkv)
     // The per-block plan of KEEP_PREC_COMP (keep_set_block_precision; the four options above are prefix shorthands that rewrite it):
     //   attn_mode[i]  attention side of block i: KEEP_ATTN_PLAIN | KEEP_ATTN_SPLIT (qkv, q/k/v storage, attention, proj as split products) |
-    //                 KEEP_ATTN_SPLIT_COMPQKV (the same with the qkv GEMM as a compensated product) | KEEP_ATTN_COMPQKV (compensated qkv only)
+    //                 KEEP_ATTN_SPLIT_COMPQKV (the same with the qkv GEMM as a compensated product) | KEEP_ATTN_COMPQKV (compensated qkv only) |
+    //                 KEEP_ATTN_PROJ_CLS (plain for every row + the CLS rows' proj again as a split product on their fp32-grade attention output)
     //   mlp_mode[i]   fc1 / fc2 of block i: KEEP_MLP_PLAIN | KEEP_MLP_SPLIT | KEEP_MLP_COMP (both MX-fp4 correction terms) | KEEP_MLP_COMP_W (the W_lo term only) |
     //                 KEEP_MLP_CLS (plain for every row + the CLS rows again as split products)
     // Which block gets what is a measured, per-checkpoint decision (tools/precision_budget.py, KEEPModel.calibrate).
@@ -234,7 +235,7 @@ struct keep_handle {
     bool any_comp() const {
         if (precision != KEEP_PREC_COMP || !vit_has_q) return false;
         for (int i = 0; i < MAX_BLOCKS && i < (vit_depth ? vit_depth : MAX_BLOCKS); ++i)
-            if (mlp_mode[i] == KEEP_MLP_COMP || mlp_mode[i] == KEEP_MLP_COMP_W || attn_mode[i] >= KEEP_ATTN_SPLIT_COMPQKV) return true;
+            if (mlp_mode[i] == KEEP_MLP_COMP || mlp_mode[i] == KEEP_MLP_COMP_W || attn_mode[i] == KEEP_ATTN_SPLIT_COMPQKV || attn_mode[i] == KEEP_ATTN_COMPQKV) return true;
         return false;
     }
 
@@ -497,6 +498,8 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     const int mlp_comp = mlp == KEEP_MLP_COMP_W ? 1 : 2;               // GemmParams.comp of the block's fc1 / fc2
     const bool mlp_cls = mlp == KEEP_MLP_CLS;                          // every row plain, then the CLS rows again as split products (below)
     const bool mlp_plain = mlp == KEEP_MLP_PLAIN || mlp_cls;
+    // KEEP_ATTN_PROJ_CLS: every row plain; the attention kernel also writes the CLS rows' output hi + lo (compact), and their proj runs again as a split product
+    const bool proj_cls = !sp && !cls_only && h->plan_attn(i) == KEEP_ATTN_PROJ_CLS && i >= h->strict_blocks;
 #ifdef KEEP_DIAGNOSTICS
     const bool skip_ln = h->dbg_skip_ln == 1 && h->dbg_calls > 3;
 #else
@@ -548,6 +551,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         a.mask = nullptr; a.batch = Bc; a.ntok = 197; a.heads = h->vit_heads; a.split = sp; a.scale = 0.125f; a.out_kt = D / 32;
         a.q_rows = cls_only ? 1 : 0;
         if (kv_only) { a.q_hi = ws.c_mlp_hi; a.q_ld = D; }
+        if (proj_cls) { a.cls_hi = ws.c_att_hi; a.cls_lo = ws.c_att_lo; }
 #ifdef KEEP_DIAGNOSTICS
         if (!(h->dbg_skip_ln == 2 && h->dbg_calls > 3))      // dbg_skip_ln = 2: skip the attention launches instead (bounds what a faster attention could gain)
 #endif
@@ -569,6 +573,10 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = mlp_lo ? xn_lo : nullptr;
     ln.out_q = mlp_q ? ws.xn_q : nullptr; ln.out_sc = mlp_q ? ws.xn_sc : nullptr; ln.out_q_hi_only = mlp == KEEP_MLP_COMP_W;
     ln.gamma = b.n2w; ln.beta = b.n2b;
+    if (proj_cls) {             // the CLS rows' residual as it enters proj (the plain proj below updates these rows too; the split result replaces that)
+        Scope sc(h, T_VIT_TAIL, s);
+        launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
+    }
     int did;
     {
         const int tag = cls_only ? T_VIT_TAIL : sp ? T_VIT_PROJ_X : T_VIT_PROJ;
@@ -581,7 +589,27 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
     }
     mark(3);
-    if (mlp_cls) {              // the CLS rows' residual as it enters the MLP (the plain fc2 below updates these rows too; the split result replaces that)
+    bool cls_ln_done = false;   // LayerNorm-2 of the compact CLS rows already written (hi + lo) by the CLS-row proj's epilogue
+    if (proj_cls) {
+        // [Bc, D] x W_proj^T as a split product on the small-M kernels: the CLS rows' attention output from the fp32 accumulators (hi + lo) against W hi + lo,
+        // + LayerScale + the residual gathered above.  With KEEP_MLP_CLS in the same block the chain simply continues on the compact rows (its LayerNorm-2 is
+        // fused into this GEMM's reduce, its final scatter writes the rows back); otherwise the rows are written back here, before LayerNorm-2 reads them.
+        Scope sc(h, T_VIT_TAIL, s);
+        GemmParams r = gemm_params(h, ws.c_att_hi, ws.c_att_lo, b.proj, Bc, true, b.proj_b);
+        r.ls = b.ls1; r.resid = ws.c_resid;
+        LnParams cl{};
+        if (mlp_cls) {
+            cl.tune = &h->tune;
+            cl.x = ws.c_resid; cl.x_stride = D; cl.rows = Bc; cl.D = D; cl.eps = 1e-6f; cl.gamma = b.n2w; cl.beta = b.n2b;
+            cl.out_hi = ws.c_xn_hi; cl.out_lo = ws.c_xn_lo; cl.out_kt = D / 32;
+            offer_ln(r, cl);
+        }
+        const int rc = run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, s, ws.splitk);
+        if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row proj GEMM launch failed");
+        cls_ln_done = mlp_cls && (rc & GEMM_DID_LN);
+        if (!mlp_cls) launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
+    }
+    if (mlp_cls && !proj_cls) { // the CLS rows' residual as it enters the MLP (the plain fc2 below updates these rows too; the split result replaces that)
         Scope sc(h, T_VIT_TAIL, s);
         launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
     }
@@ -630,7 +658,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         cl.tune = &h->tune;
         cl.x = ws.c_resid; cl.x_stride = D; cl.rows = Bc; cl.D = D; cl.eps = 1e-6f; cl.gamma = b.n2w; cl.beta = b.n2b;
         cl.out_hi = ws.c_xn_hi; cl.out_lo = ws.c_xn_lo; cl.out_kt = D / 32;
-        if (launch_layernorm(cl, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
+        if (!cls_ln_done && launch_layernorm(cl, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
         GemmParams p = gemm_params(h, ws.c_xn_hi, ws.c_xn_lo, b.fc1, Bc, true, b.fc1_b);
         p.out_hi = ws.c_mlp_hi; p.out_lo = ws.c_mlp_lo; p.out_kt = h->vit_F / 32;
         if (run_gemm(h, T_VIT_TAIL, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc1 GEMM launch failed");
@@ -1279,6 +1307,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "gemm_persistent") { if (v < 0 || v > 1024) return h->fail(KEEP_EINVAL, "gemm_persistent must be 0..1024"); t.gemm_persistent = v; }
     else if (n == "gemm_splitk_tiles") { if (v < 0 || v > 256) return h->fail(KEEP_EINVAL, "gemm_splitk_tiles must be 0..256"); t.gemm_splitk_tiles = v; }
     else if (n == "sgemv_m") { if (v < 0 || v > 16) return h->fail(KEEP_EINVAL, "sgemv_m must be 0..16"); t.sgemv_m = v; }
+    else if (n == "skinny_wide") { t.skinny_wide = v ? 1 : 0; }
     else if (n == "gemm_skinny_m") { if (v < 0 || v > SKINNY_MAX_M) return h->fail(KEEP_EINVAL, "gemm_skinny_m must be 0..%d", SKINNY_MAX_M); t.gemm_skinny_m = v; }
     else if (n == "lane_min_tiles") { if (v < 6) return h->fail(KEEP_EINVAL, "lane_min_tiles must be >= 6"); h->lane_min_tiles = v; }
     else if (n == "lane_skew") { if (v < 0 || v > 5) return h->fail(KEEP_EINVAL, "lane_skew must be 0..5"); h->lane_skew = v; }
@@ -1321,6 +1350,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "streams") return h->n_streams;
     if (n == "graphs") return h->use_graphs;
     if (n == "gemm_skinny_m") return t.gemm_skinny_m;
+    if (n == "skinny_wide") return t.skinny_wide;
     if (n == "sgemv_m") return t.sgemv_m;
     if (n == "gemm_splitk_tiles") return t.gemm_splitk_tiles;
     if (n == "gemm_persistent") return t.gemm_persistent;
@@ -1341,7 +1371,7 @@ double keep_get_option(keep_handle* h, const char* name) {
 int keep_set_block_precision(keep_handle* h, int block, int attn_mode, int mlp_mode) {
     if (!h) return KEEP_EINVAL;
     if (block < 0 || block >= keep_handle::MAX_BLOCKS) return h->fail(KEEP_EINVAL, "block %d outside 0..%d", block, keep_handle::MAX_BLOCKS - 1);
-    if (attn_mode > KEEP_ATTN_COMPQKV || mlp_mode > KEEP_MLP_CLS) return h->fail(KEEP_EINVAL, "attn_mode %d (0..3) / mlp_mode %d (0..4); negative = leave", attn_mode, mlp_mode);
+    if (attn_mode > KEEP_ATTN_PROJ_CLS || mlp_mode > KEEP_MLP_CLS) return h->fail(KEEP_EINVAL, "attn_mode %d (0..4) / mlp_mode %d (0..4); negative = leave", attn_mode, mlp_mode);
     ++h->opt_epoch;               // captured graphs bake the plan in
     if (attn_mode >= 0) h->attn_mode[block] = (unsigned char)attn_mode;
     if (mlp_mode >= 0) h->mlp_mode[block] = (unsigned char)mlp_mode;

@@ -71,6 +71,85 @@ void gemm_skinny_partial_kernel(GemmParams p, float* __restrict__ part, int step
     }
 }
 
+// The same product for 64 <= M (the CLS-row chain of the image tower: M = tiles of a lane, three operand segments): 128 x 128 output tiles, one
+// 64 x 64 quadrant (2 x 2 MFMA tiles) per wave.  A wave of the kernel above loads one A and one W fragment per MFMA -- 16 FLOP per operand byte, all of
+// it L2 traffic (28 us for [256, 1024] x [1024, 4096] x 3 segments: the L2, not the matrix pipes) --; here every fragment feeds two MFMAs.
+constexpr int SK2_BM = 128, SK2_BN = 128;
+
+__global__ __launch_bounds__(256)
+void gemm_skinny_partial_wide_kernel(GemmParams p, float* __restrict__ part, int steps_per_split) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * SK2_BN + wn * 64, m0 = blockIdx.y * SK2_BM + wm * 64, split = blockIdx.z;
+    const int KT = p.K / 32;
+    const int kt0 = split * steps_per_split;
+    const int kt1 = min(KT, kt0 + steps_per_split);
+    const int r = lane & 31, half = lane >> 5;
+    int64_t a_base[2], w_base[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int m = m0 + f * 32 + r, n = n0 + f * 32 + r;       // (rows past M lie inside the operand's 256-row padding: computed, never stored)
+        a_base[f] = (int64_t)(m >> 8) * KT * 8192 + ((m & 255) << 5) + half * 8;
+        w_base[f] = (int64_t)(n >> 8) * KT * 8192 + ((n & 255) << 5) + half * 8;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // one flat walk over (segment, K slice) with the NEXT step's eight 16-byte fragments in flight under this step's eight MFMAs: a workgroup of this
+    // kernel is latency-bound (a few dozen dependent steps, each a round trip to the L2 / HBM), not bandwidth- or pipe-bound
+    const int nk = kt1 - kt0, steps = nk > 0 ? nk * p.nseg : 0;
+    auto frag = [&](int st, f16x8 (&a)[2][2], f16x8 (&w)[2][2]) {
+        const int seg = st / nk, kt = kt0 + (st - seg * nk);
+        const f16* A = seg == 1 ? p.a_lo : p.a_hi;
+        const f16* W = seg == 2 ? p.w_lo : p.w_hi;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                a[f][k] = *reinterpret_cast<const f16x8*>(A + a_base[f] + (int64_t)kt * 8192 + k * 16);
+                w[f][k] = *reinterpret_cast<const f16x8*>(W + w_base[f] + (int64_t)kt * 8192 + k * 16);
+            }
+    };
+    auto fma8 = [&](const f16x8 (&a)[2][2], const f16x8 (&w)[2][2]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j][k], a[i][k], acc[i][j], 0, 0, 0);
+    };
+    f16x8 a0[2][2], w0[2][2], a1[2][2], w1[2][2];
+    if (steps > 0) frag(0, a0, w0);
+    int st = 0;
+    for (; st + 2 <= steps; st += 2) {
+        frag(st + 1, a1, w1);
+        fma8(a0, w0);
+        if (st + 2 < steps) frag(st + 2, a0, w0);
+        fma8(a1, w1);
+    }
+    if (st < steps) fma8(a0, w0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + i * 32 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* o = part + ((int64_t)split * p.M + m) * p.N + n0 + j * 32 + half * 4;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e];
+                *reinterpret_cast<f32x4*>(o + rg * 8) = v;
+            }
+        }
+    }
+}
+
 // Sum of the S partials (s = 0, 1, ... in that order) + the fused epilogue of gemm_f16_v2.hip.  One thread per 4 columns.
 template <int EPI>
 __global__ __launch_bounds__(256)
@@ -186,9 +265,12 @@ void gemm_skinny_reduce_ln_kernel(GemmParams p, const float* __restrict__ part, 
 }  // namespace keepk
 using namespace keepk;
 
-int skinny_splits(int M, int N, int K) {
-    const int tiles = ((M + SK_BM - 1) / SK_BM) * (N / SK_BN), ks = K / 32;
-    int S = (768 + tiles - 1) / tiles;
+bool skinny_wide(int M, const KeepTune* t = nullptr) { return M >= 64 && (!t || t->skinny_wide); }       // the 128 x 128 kernel from 64 rows up (below, its half-empty row blocks cost more than the fragment reuse saves)
+
+int skinny_splits(int M, int N, int K, const KeepTune* t = nullptr) {
+    const bool wide = skinny_wide(M, t);
+    const int tiles = wide ? ((M + SK2_BM - 1) / SK2_BM) * (N / SK2_BN) : ((M + SK_BM - 1) / SK_BM) * (N / SK_BN), ks = K / 32;
+    int S = ((wide ? 256 : 768) + tiles - 1) / tiles;      // (wide: one 128 x 128 tile per CU -- fewer, longer K walks and less partial-sum traffic for the reduce)
     if (S > ks / 2) S = ks / 2;
     if (S > 16) S = 16;
     return S < 1 ? 1 : S;
@@ -199,11 +281,12 @@ size_t skinny_ws_bytes(int M, int N, int K) { return (size_t)skinny_splits(M, N,
 // Returns -1 when the shape is not eligible (caller falls back to the big kernel), else 0 or GEMM_DID_LN.
 int launch_gemm_f16_skinny(const GemmParams& p, int epi, float* ws, size_t ws_bytes, hipStream_t s) {
     if (!ws || p.N % SK_BN || p.K % 32 || p.M < 1) return -1;
-    const int S = skinny_splits(p.M, p.N, p.K);
+    const int S = skinny_splits(p.M, p.N, p.K, p.tune);
     if ((size_t)S * p.M * p.N * sizeof(float) > ws_bytes) return -1;
     const int KT = p.K / 32, per = (KT + S - 1) / S;
-    dim3 grid(p.N / SK_BN, (p.M + SK_BM - 1) / SK_BM, S), block(256);
-    hipLaunchKernelGGL(gemm_skinny_partial_kernel, grid, block, 0, s, p, ws, per);
+    dim3 block(256);
+    if (skinny_wide(p.M, p.tune)) hipLaunchKernelGGL(gemm_skinny_partial_wide_kernel, dim3(p.N / SK2_BN, (p.M + SK2_BM - 1) / SK2_BM, S), block, 0, s, p, ws, per);
+    else hipLaunchKernelGGL(gemm_skinny_partial_kernel, dim3(p.N / SK_BN, (p.M + SK_BM - 1) / SK_BM, S), block, 0, s, p, ws, per);
     return launch_gemm_splitk_reduce(p, epi, ws, S, s);
 }
 

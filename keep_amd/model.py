@@ -42,18 +42,21 @@ CONFIDENCE = 0.99
 PROBE_RMS_MARGIN = 1.02
 # Milliseconds a knob adds to a 256-tile encode step on an MI355X (two lanes; tools/precision_budget.py measures them, profiles/r05_precision_budget.md):
 # what the greedy of budget="measured" divides a knob's variance share by.  Only the RATIOS matter.
-KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.10}
+KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "attn_proj_cls": 0.03, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.10}
 # Share of a site's rounding variance that survives a treatment when it is not measured on the loaded weights (same tool, bench weights): both
 # MX-fp4 correction terms remove ~96 % of an MLP's share, the W_lo term alone 40-55 %; a compensated qkv inside a split attention side leaves 1-2 %
 MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_CLS: 0.1, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}
-ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_SPLIT_COMPQKV: 0.015, _lib.ATTN_SPLIT: 0.0}
+ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_PROJ_CLS: 0.55, _lib.ATTN_SPLIT_COMPQKV: 0.015, _lib.ATTN_SPLIT: 0.0}
 # The treatments the greedy of budget="measured" may use.  Measured on the bench weights (profiles/r05_precision_budget.md): the W_lo-only MLP form
 # removes ~45 % of a block's MLP share for 57 % of the cost of both terms, and a compensated qkv alone ~35 % of an attention side's share at 1 ms per
 # percent of variance against 0.45 for MLP blocks -- neither ever wins a greedy step, so they are off by default (``knobs=`` switches them on).
 # KEEP_MLP_CLS (every row plain, the CLS row of every tile again as split products) is the cheap one: the feature is pooled from the CLS rows, whose
 # own rounding errors reach it directly while the other 196 rows' only arrive through attention averages -- what it leaves of a block's MLP share is
 # measured per block (0.5-2 % on the bench weights).
-DEFAULT_KNOBS = {"attn": (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_CLS, _lib.MLP_COMP)}
+# KEEP_ATTN_PROJ_CLS (round 6) is the attention side's counterpart: on spatially correlated tiles ~70 % of an attention side's rounding error is its proj
+# GEMM's (tools/attn_site_study.py), and redoing the CLS row's proj as a split product on its fp32-grade attention output removes what a full CLS-row
+# treatment of the attention side would -- for one more small GEMM in the CLS-row chain (measured per block and tile group, like KEEP_MLP_CLS).
+DEFAULT_KNOBS = {"attn": (_lib.ATTN_PROJ_CLS, _lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_CLS, _lib.MLP_COMP)}
 
 Plan = List[Tuple[int, int]]
 
@@ -408,8 +411,8 @@ class KEEPModel:
         """The per-block plan of the 'comp' mode: ``plan[i] = (attention-side mode, MLP mode)`` of ViT block i (``_lib.ATTN_*`` / ``_lib.MLP_*``,
         = KEEP_ATTN_* / KEEP_MLP_* of include/keep_hip.h).  Blocks beyond ``len(plan)`` run plain fp16 passes."""
         plan = [(int(a), int(m)) for a, m in plan]
-        if any(not (0 <= a <= 3 and 0 <= m <= 4) for a, m in plan) or len(plan) > 64:
-            raise ValueError("a plan holds at most 64 (attn_mode 0..3, mlp_mode 0..4) pairs")
+        if any(not (0 <= a <= 4 and 0 <= m <= 4) for a, m in plan) or len(plan) > 64:
+            raise ValueError("a plan holds at most 64 (attn_mode 0..4, mlp_mode 0..4) pairs")
         pre = plan_prefix(plan)
         for k in self._PLAN_SHORTHANDS:
             self._options.pop(k, None)
@@ -497,8 +500,8 @@ class KEEPModel:
         anisotropy factor for the plan: the median over the groups of (rms against the probe's prompt bank / isotropic rms), at least 1 (error
         vectors are not isotropic; but the bank rms of a group of near-identical tiles is one random draw, so no single group's ratio is trusted).
         ``margin_g`` >= PROBE_RMS_MARGIN = two standard errors of the group's mean squared error, estimated from its tile-to-tile spread (one tile's
-        cosines share ONE error vector).  ``tail_g`` >= 1 only when the group's own maximum is larger than a Gaussian sample of its size allows at
-        99 %.  ``model.calibration`` reports the prediction, the per-group figures and the ``exceedance_probability`` of the chosen plan.
+        cosines share ONE error vector).  ``tail_g`` >= 1 only when the group's own maximum is larger than its per-tile mixture allows a sample of the
+        probe's size at 99 %.  ``model.calibration`` reports the prediction, the per-group figures and the ``exceedance_probability`` of the chosen plan.
         Candidates: ``budget="ladder"`` walks ``COMP_LADDER`` (prefix plans); ``budget="measured"`` first measures, on these weights and per group,
         the variance share of every block's attention side and MLP (one split-product encode per block and half with that one site downgraded),
         then builds the plan greedily -- each step the upgrade that lowers the worst group's predicted variance most per millisecond
@@ -582,8 +585,7 @@ class KEEPModel:
                 # the tile is the sample); the rule holds the plan to two of them, at least PROBE_RMS_MARGIN
                 se = float(eg.std()) / math.sqrt(nt) / ms_iso if nt > 1 and ms_iso > 0 else 0.0
                 margin = max(PROBE_RMS_MARGIN, math.sqrt(1.0 + 2.0 * se))
-                tail = max(1.0, (mx / rms_bank) / max_sigmas_quantile(nt * bank.shape[0], 0.99)) if rms_bank > 0 else 1.0
-                rows.append([name, mx, rms_bank, rms_iso, margin, tail, nt])
+                rows.append([name, mx, rms_bank, rms_iso, margin, 1.0, nt])
             # error vectors are not isotropic: against a bank of real prompts the rms can sit 5-10 % above (or below) the isotropic figure.  ONE
             # factor for the plan, the MEDIAN over the groups of bank rms / isotropic rms, at least 1: a group of near-identical tiles (glass) has
             # near-identical error vectors, and against a bank of similar prompts its bank rms is a single random draw, not an rms
@@ -592,6 +594,11 @@ class KEEPModel:
             per_group, worst = {}, None
             for (name, mx, rms_bank, rms_iso, margin, tail, nt), (_, idx) in zip(rows, members):
                 rms = rms_iso * aniso
+                # heavier tails than the model assumes show as a probe maximum above what the SAME per-tile mixture allows a sample of the probe's
+                # size at 99 %: then every sigma is stretched by the ratio (measured against the isotropic per-tile figures, not against the
+                # group's bank rms -- for a group of near-identical tiles that is a single random draw)
+                allowed = mixture_max_quantile((e2[idx].double().sqrt() * aniso).tolist(), nt * bank.shape[0], 0.99)
+                tail = max(1.0, mx / allowed) if allowed > 0 else 1.0
                 # the group's tiles are not equally hard: the population maximum is predicted from the per-tile spread (mixture_max_quantile),
                 # every tile's isotropic error standing for population / nt cosines; `eff` = the homoscedastic rms that predicts the same maximum
                 sig = (e2[idx].double().sqrt() * (aniso * margin * tail)).tolist()
@@ -738,18 +745,24 @@ class KEEPModel:
         for mode in (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_COMPQKV):
             fr = [ratio(minus_floor(var_of(i, (mode, _lib.MLP_SPLIT))), attn[i]) for i in sorted({0, depth // 2})]
             res_a[mode] = [max(f[g] for f in fr) for g in range(G)]
+        # ... and so does what the CLS-row proj leaves of an attention side (nearly all of it in block 0 of N(0,1) tiles, under half on correlated tiles)
+        pcls_left = [ratio(minus_floor(var_of(i, (_lib.ATTN_PROJ_CLS, _lib.MLP_SPLIT))), attn[i]) for i in range(depth)]
         r3 = lambda v: float(f"{v:.3e}")
         r4 = lambda v: float(f"{v:.4f}")
         by_group = {}
         for g, (name, idx) in enumerate(members):
             rm = {int(k): r4(v[g]) for k, v in res_m.items()}
             rm[int(_lib.MLP_CLS)] = [r4(cls_left[i][g]) for i in range(depth)]
+            ra = {int(k): r4(v[g]) for k, v in res_a.items()}
+            ra[int(_lib.ATTN_PROJ_CLS)] = [r4(pcls_left[i][g]) for i in range(depth)]
             by_group[name] = {"attn": [r3(attn[i][g]) for i in range(depth)], "mlp": [r3(mlp[i][g]) for i in range(depth)], "floor": r3(floor[g]),
-                              "residual_mlp": rm, "residual_attn": {int(k): r4(v[g]) for k, v in res_a.items()}, "probe_tiles": int(idx.numel())}
+                              "residual_mlp": rm, "residual_attn": ra, "probe_tiles": int(idx.numel())}
         worst_m = {int(k): r4(max(v)) for k, v in res_m.items()}
         worst_m[int(_lib.MLP_CLS)] = [r4(max(cls_left[i])) for i in range(depth)]
+        worst_a = {int(k): r4(max(v)) for k, v in res_a.items()}
+        worst_a[int(_lib.ATTN_PROJ_CLS)] = [r4(max(pcls_left[i])) for i in range(depth)]
         return {"attn": [r3(max(attn[i])) for i in range(depth)], "mlp": [r3(max(mlp[i])) for i in range(depth)], "floor": r3(max(floor)),
-                "residual_mlp": worst_m, "residual_attn": {int(k): r4(max(v)) for k, v in res_a.items()}, "probe_tiles": int(tiles.shape[0]),
+                "residual_mlp": worst_m, "residual_attn": worst_a, "probe_tiles": int(tiles.shape[0]),
                 "groups": [name for name, _ in members], "by_group": by_group}
 
     @staticmethod
@@ -763,14 +776,15 @@ class KEEPModel:
         res_a = [{int(k): v for k, v in g["residual_attn"].items()} for g in groups]
         res_m = [{int(k): v for k, v in g["residual_mlp"].items()} for g in groups]
         left_m = lambda g, i, mode: (res_m[g][mode][i] if isinstance(res_m[g][mode], (list, tuple)) else res_m[g][mode])
-        cost_a = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"], _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"],
-                  _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
+        left_a = lambda g, i, mode: (res_a[g][mode][i] if isinstance(res_a[g][mode], (list, tuple)) else res_a[g][mode])
+        cost_a = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_PROJ_CLS: KNOB_COST_MS["attn_proj_cls"], _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"],
+                  _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"], _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
         cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_CLS: KNOB_COST_MS["mlp_cls"], _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"],
                   _lib.MLP_SPLIT: 3.0 * KNOB_COST_MS["mlp_comp"]}
         am, mm = [_lib.ATTN_PLAIN] * depth, [_lib.MLP_PLAIN] * depth
 
         def predicted():
-            return [groups[g]["floor"] + sum(groups[g]["attn"][i] * res_a[g][am[i]] + groups[g]["mlp"][i] * left_m(g, i, mm[i]) for i in range(depth))
+            return [groups[g]["floor"] + sum(groups[g]["attn"][i] * left_a(g, i, am[i]) + groups[g]["mlp"][i] * left_m(g, i, mm[i]) for i in range(depth))
                     for g in range(G)]
 
         cur = predicted()
@@ -779,7 +793,8 @@ class KEEPModel:
             best, gain, best_sum, gain_sum = None, 0.0, None, 0.0
             top = max(cur)
             for i in range(depth):
-                cands = [(am, a, cost_a[a] - cost_a[am[i]], [groups[g]["attn"][i] * (res_a[g][am[i]] - res_a[g][a]) for g in range(G)]) for a in knobs.get("attn", ())]
+                cands = [(am, a, cost_a[a] - cost_a[am[i]], [groups[g]["attn"][i] * (left_a(g, i, am[i]) - left_a(g, i, a)) for g in range(G)]) for a in knobs.get("attn", ())
+                         if a in res_a[0]]
                 cands += [(mm, m, cost_m[m] - cost_m[mm[i]], [groups[g]["mlp"][i] * (left_m(g, i, mm[i]) - left_m(g, i, m)) for g in range(G)]) for m in knobs.get("mlp", ())]
                 for target, mode, dc, dv in cands:
                     if dc <= 0:

@@ -217,3 +217,36 @@ def test_bias_compensation_off_its_own_distribution():
     assert cal["precision"] == "comp" and cal["bias_correction"] and cal["predicted_max_abs_dcos"] <= COS_TOL
     for family in ("background", "he_crops"):
         _slide_checks(bench.structured_slide_parity(m, dev, family, n=12_500, seed=7000), family + " (bias compensation from N(0,1) tiles)")
+
+
+@pytest.mark.gpu
+def test_proj_cls_knob(bench_model):
+    """KEEP_ATTN_PROJ_CLS: every row plain, the CLS rows' proj again as a split product on the hi + lo attention output the attention kernel keeps for
+    them.  On correlated tiles it removes a good part of the attention side's share (CPU emulation: tools/attn_site_study.py); it composes with
+    KEEP_MLP_CLS (one chain on the compact rows); small batches (the generic attention kernel, the small-M GEMM path) take it too."""
+    from keep_amd import _lib
+    m, _ = bench_model
+    own = m.get_plan()
+    x = synth_tile_family("he_crops", 0, 1024, "cuda:0", seed=7003)
+    iso = lambda f, ref: float((f - ref).pow(2).sum(1).mean().div(768).sqrt())
+    enc = lambda t: torch.cat([m.encode_image_uint8(t[i:i + 256]) for i in range(0, t.shape[0], 256)])
+    try:
+        m.set_precision("strict")
+        ref = enc(x)
+        m.set_precision("comp")
+        res = {}
+        for name, plan in (("plain", (_lib.ATTN_PLAIN, _lib.MLP_PLAIN)), ("proj_cls", (_lib.ATTN_PROJ_CLS, _lib.MLP_PLAIN)), ("mlp_cls", (_lib.ATTN_PLAIN, _lib.MLP_CLS)),
+                           ("both_cls", (_lib.ATTN_PROJ_CLS, _lib.MLP_CLS)), ("proj_cls+mlp_split", (_lib.ATTN_PROJ_CLS, _lib.MLP_SPLIT))):
+            m.set_plan([plan] * 24)
+            assert m.get_plan() == [plan] * 24
+            res[name] = iso(enc(x), ref)
+        print("[he_crops, 1024 tiles, isotropic rms vs strict] " + "  ".join(f"{k} {v:.3e}" for k, v in res.items()))
+        assert res["proj_cls"] < 0.92 * res["plain"] and res["both_cls"] < 0.85 * res["mlp_cls"] and res["both_cls"] < 0.6 * res["plain"]
+        # small batches: 7 tiles (generic attention kernel, everything on the small-M path) and 40 (one lane of the big kernels)
+        m.set_plan([(_lib.ATTN_PROJ_CLS, _lib.MLP_CLS)] * 24)
+        for n in (1, 7, 40):
+            f = m.encode_image_uint8(x[:n])
+            assert iso(f, ref[:n]) < 1.5 * res["both_cls"] + 2e-6, n
+    finally:
+        m.set_precision("comp")
+        m.set_plan(own)

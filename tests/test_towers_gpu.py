@@ -521,6 +521,24 @@ def test_bench_sized_batch_is_position_independent(no_splitk, precision):
     assert (big[(idx == 0).nonzero()[0, 0]].cpu() - ref[0]).norm() < 3e-3
 
 
+def test_calls_of_512_and_4096_tiles_are_position_independent(no_splitk):
+    """Calls of >= 512 tiles run as chunks of two 256-tile lanes (what bench.py's config-3 / config-4 / slide legs and
+    `keep_amd.distributed.encode_tiles_sharded` now pass per call: +1.7 % over 256-tile calls, profiles/r05_step_boundary_bubble.txt).  Same property as above at
+    those sizes: every copy of a tile has the same bits wherever it sits, in whichever chunk and lane; against the 256-tile call (lanes of 128: the CLS-row
+    chain sums its K slices in another order) the features agree to fp32 rounding."""
+    sd = synth_state_dict(KEEPShape(), seed=41, text=False)
+    m = make_model(sd, "comp")
+    base = synth_tiles(8, seed=42).to(torch.bfloat16).cuda()
+    ref256 = m.encode_image(base[(torch.arange(256) % 8).cuda()])[:8]
+    for n in (512, 4096):
+        idx = (torch.randperm(n, generator=torch.Generator().manual_seed(n)) % 8).cuda()
+        big = m.encode_image(base[idx])
+        for k in range(8):
+            rows = big[idx == k]
+            assert torch.equal(rows, rows[:1].expand_as(rows)), (n, k)
+            assert (rows[0] - ref256[k]).abs().max() < 2e-6, (n, k)
+
+
 def test_compensated_mode_takes_the_fp4_path_on_bench_sized_lanes(small, text_bank):
     """Lanes of >= 32 tiles run fc1 / fc2 as fp16 pass + MX-fp4 correction terms (smaller calls use split products, which
     the other tests cover): 64 tiles = two lanes of 32.  Held to the tolerance, and required to beat the plain fp16 mode."""
@@ -858,6 +876,13 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     assert got["mlp comp"] < got["mlp comp, W_lo term"] < e_plain and got["attn split"] <= got["attn split, comp qkv"] * 1.05 and got["attn split, comp qkv"] < got["comp qkv only"]
     # the CLS rows redone as split products: the pooled feature is one of them, so most of the MLP's error share goes with 0.5 % of the rows
     assert got["mlp plain + CLS rows split"] < 0.93 * e_plain
+    # KEEP_ATTN_PROJ_CLS (round 6): plain rows + the CLS rows' proj again as a split product; alone and chained with the CLS-row MLP (N(0,1) tiles: a small
+    # share -- what it does on correlated tiles is measured in tests/test_tile_families.py)
+    m.set_plan([(4, 0)] * depth); e_pc = err(m.encode_image(x)); assert m.get_plan() == [(4, 0)] * depth
+    m.set_plan([(4, 4)] * depth); e_pc_cls = err(m.encode_image(x))
+    assert torch.equal(m.encode_image(x), m.encode_image(x))
+    print(f"[plans, depth {depth}] CLS rows' proj split: {e_pc:.3e}; + CLS-row MLP: {e_pc_cls:.3e}")
+    assert e_split * 0.9 <= e_pc < 1.02 * e_plain and e_pc_cls < 1.02 * got["mlp plain + CLS rows split"]
     m.set_plan([(1, 4)] * depth); e_cls = err(m.encode_image(x))
     m.set_plan([(1, 0)] * depth); e_attn_only = err(m.encode_image(x))
     m.set_plan([(1, 2)] * depth); e_comp = err(m.encode_image(x))
@@ -873,7 +898,7 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     m.set_option("comp_mlp_blocks", 1)
     assert m.get_plan() == prefix_plan(depth, 0, 1) and m.get_option("plan_custom") == 0
     lib = _lib.load()
-    for bad in ((0, 4, 0), (0, 0, 5), (64, 1, 1), (-1, 1, 1)):
+    for bad in ((0, 5, 0), (0, 0, 5), (64, 1, 1), (-1, 1, 1)):
         assert lib.keep_set_block_precision(m._handle, *bad) == _lib.KEEP_EINVAL
     with pytest.raises(ValueError):
         m.set_plan([(0, 7)])
