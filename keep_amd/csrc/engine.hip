@@ -179,6 +179,18 @@ struct keep_handle {
     int n_streams = 2;           // concurrent sub-batches inside keep_encode_image (1 = everything on the caller's stream)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    // The CLS-row chain (KEEP_MLP_CLS, with KEEP_ATTN_PROJ_CLS in front of it) of a lane on a stream of its own: 7-8 small DEPENDENT launches per block.  In
+    // the lane's own stream each of them queues behind whatever persistent GEMM of the other lane holds the CUs, the lane advances one small kernel per big
+    // kernel of its neighbour, and the two lanes end up taking turns -- with the chain in all 24 blocks the two-lane step was the single-stream sum (round 6).
+    // Forked after the residual gather, joined before the next block: the chain runs under the lane's own LayerNorm-2 / fc1 / fc2.
+    // MEASURED NEGATIVE, off: 6 334 against 7 086 tiles/s on one box (tools/ab_options.py --calibrate --arm base --arm cls_side_stream=0, three rotated rounds,
+    // profiles/r06_ab_cls_side_stream.txt): the three cross-stream waits per block and lane (144 per step) cost more than the chain's exposure -- a
+    // cross-queue dependency is a barrier packet the next persistent GEMM sits behind.  The premise was wrong too: the kernel times of a step add up to
+    // 37.8 ms on one stream and the two-lane step takes 37.7 -- the lanes already pack the GPU back to back; what the chains cost is their own latency.
+    int cls_side_stream = 0;
+    hipStream_t aux_cls[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_cls[4][3] = {};
+    float* cls_splitk[4] = {nullptr, nullptr, nullptr, nullptr};     // the chain's own K-slice scratch (the lane's is in use by its main stream)
 
     // workspace arena
     char* arena = nullptr;
@@ -450,6 +462,7 @@ struct VitLane {
     const void* pixels; int pix_dtype; int Bc; float* out; hipStream_t s; VitWs ws; bool cls_compact = false;
     hipEvent_t skew_ev = nullptr; int skew_stage = 0;     // recorded after stage `skew_stage` of block 0 (lane_skew)
     bool xn_ready = false;                                // the previous block's fc2 already wrote this block's LayerNorm-1 output
+    hipStream_t cs = nullptr; hipEvent_t ce[3] = {nullptr, nullptr, nullptr}; float* cs_splitk = nullptr;      // side stream of the CLS-row chain (nullable)
 };
 
 int vit_begin(keep_handle* h, VitLane& L) {
@@ -590,11 +603,22 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     }
     mark(3);
     bool cls_ln_done = false;   // LayerNorm-2 of the compact CLS rows already written (hi + lo) by the CLS-row proj's epilogue
+    // the chain's stream: the lane's side stream when the block ends with the CLS-row MLP (whose scatter is the join), else the lane's own
+    const bool side = mlp_cls && L.cs != nullptr;
+    hipStream_t cs = side ? L.cs : s;
+    float* c_splitk = side ? L.cs_splitk : ws.splitk;
+    if (mlp_cls && !proj_cls) { // the CLS rows' residual as it enters the MLP (the plain fc2 below updates these rows too; the split result replaces that)
+        Scope sc(h, T_VIT_TAIL, s);
+        launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
+    }
+    if (side) {                 // fork: everything the chain reads (the gathered residual, the CLS rows' attention output) is queued on the lane's stream before this point
+        if (hipEventRecord(L.ce[0], s) != hipSuccess || hipStreamWaitEvent(cs, L.ce[0], 0) != hipSuccess) return h->fail(KEEP_EHIP, "CLS-row chain: fork failed");
+    }
     if (proj_cls) {
         // [Bc, D] x W_proj^T as a split product on the small-M kernels: the CLS rows' attention output from the fp32 accumulators (hi + lo) against W hi + lo,
         // + LayerScale + the residual gathered above.  With KEEP_MLP_CLS in the same block the chain simply continues on the compact rows (its LayerNorm-2 is
         // fused into this GEMM's reduce, its final scatter writes the rows back); otherwise the rows are written back here, before LayerNorm-2 reads them.
-        Scope sc(h, T_VIT_TAIL, s);
+        Scope sc(h, T_VIT_TAIL, cs);
         GemmParams r = gemm_params(h, ws.c_att_hi, ws.c_att_lo, b.proj, Bc, true, b.proj_b);
         r.ls = b.ls1; r.resid = ws.c_resid;
         LnParams cl{};
@@ -604,14 +628,27 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
             cl.out_hi = ws.c_xn_hi; cl.out_lo = ws.c_xn_lo; cl.out_kt = D / 32;
             offer_ln(r, cl);
         }
-        const int rc = run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, s, ws.splitk);
+        const int rc = run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, cs, c_splitk);
         if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row proj GEMM launch failed");
         cls_ln_done = mlp_cls && (rc & GEMM_DID_LN);
         if (!mlp_cls) launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
     }
-    if (mlp_cls && !proj_cls) { // the CLS rows' residual as it enters the MLP (the plain fc2 below updates these rows too; the split result replaces that)
-        Scope sc(h, T_VIT_TAIL, s);
-        launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
+    if (mlp_cls) {
+        // The CLS row of every tile once more, as split products on the small-M kernels: LayerNorm-2 -> fc1 + GELU -> fc2 + LayerScale + residual on the
+        // compact [Bc, D] rows (gathered after proj, or left there by the CLS-row proj), then written over the rows the plain fc2 produced.  0.5 % of the
+        // rows; the feature is pooled from them.  On the side stream this runs under the lane's own LayerNorm-2 / fc1 / fc2 below.
+        Scope sc(h, T_VIT_TAIL, cs);
+        LnParams cl{};
+        cl.tune = &h->tune;
+        cl.x = ws.c_resid; cl.x_stride = D; cl.rows = Bc; cl.D = D; cl.eps = 1e-6f; cl.gamma = b.n2w; cl.beta = b.n2b;
+        cl.out_hi = ws.c_xn_hi; cl.out_lo = ws.c_xn_lo; cl.out_kt = D / 32;
+        if (!cls_ln_done && launch_layernorm(cl, cs)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
+        GemmParams p = gemm_params(h, ws.c_xn_hi, ws.c_xn_lo, b.fc1, Bc, true, b.fc1_b);
+        p.out_hi = ws.c_mlp_hi; p.out_lo = ws.c_mlp_lo; p.out_kt = h->vit_F / 32;
+        if (run_gemm(h, T_VIT_TAIL, p, EPI_GELU_F16, cs, c_splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc1 GEMM launch failed");
+        GemmParams r = gemm_params(h, ws.c_mlp_hi, ws.c_mlp_lo, b.fc2, Bc, true, b.fc2_b);
+        r.ls = b.ls2; r.resid = ws.c_resid;
+        if (run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, cs, c_splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc2 GEMM launch failed");
     }
     if (!(did & GEMM_DID_LN) && !skip_ln) {
         Scope sc(h, T_VIT_LN, s);
@@ -650,22 +687,11 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "fc2 GEMM launch failed");
         L.xn_ready = (rc & GEMM_DID_LN) != 0;
     }
-    if (mlp_cls) {
-        // The CLS row of every tile once more, as split products on the small-M kernels: LayerNorm-2 -> fc1 + GELU -> fc2 + LayerScale + residual on the
-        // compact [Bc, D] copy taken after proj, then written over the rows the plain fc2 produced.  0.5 % of the rows; the feature is pooled from them.
-        Scope sc(h, T_VIT_TAIL, s);
-        LnParams cl{};
-        cl.tune = &h->tune;
-        cl.x = ws.c_resid; cl.x_stride = D; cl.rows = Bc; cl.D = D; cl.eps = 1e-6f; cl.gamma = b.n2w; cl.beta = b.n2b;
-        cl.out_hi = ws.c_xn_hi; cl.out_lo = ws.c_xn_lo; cl.out_kt = D / 32;
-        if (!cls_ln_done && launch_layernorm(cl, s)) return h->fail(KEEP_EUNSUPPORTED, "layernorm width %d", D);
-        GemmParams p = gemm_params(h, ws.c_xn_hi, ws.c_xn_lo, b.fc1, Bc, true, b.fc1_b);
-        p.out_hi = ws.c_mlp_hi; p.out_lo = ws.c_mlp_lo; p.out_kt = h->vit_F / 32;
-        if (run_gemm(h, T_VIT_TAIL, p, EPI_GELU_F16, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc1 GEMM launch failed");
-        GemmParams r = gemm_params(h, ws.c_mlp_hi, ws.c_mlp_lo, b.fc2, Bc, true, b.fc2_b);
-        r.ls = b.ls2; r.resid = ws.c_resid;
-        if (run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, s, ws.splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc2 GEMM launch failed");
-        launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
+    if (mlp_cls) {              // the join: the chain's rows replace what the plain fc2 wrote (ordered after it), and the lane goes on behind the scatter
+        Scope sc(h, T_VIT_TAIL, cs);
+        if (side && (hipEventRecord(L.ce[1], s) != hipSuccess || hipStreamWaitEvent(cs, L.ce[1], 0) != hipSuccess)) return h->fail(KEEP_EHIP, "CLS-row chain: join failed");
+        launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, cs);
+        if (side && (hipEventRecord(L.ce[2], cs) != hipSuccess || hipStreamWaitEvent(s, L.ce[2], 0) != hipSuccess)) return h->fail(KEEP_EHIP, "CLS-row chain: join failed");
     }
     mark(5);
     return KEEP_OK;
@@ -1123,6 +1149,13 @@ int encode_image_run(keep_handle* h, const void* pixels, int pix_dtype, int64_t 
             x.out = out + lo * h->proj_dim;
             x.s = lanes > 1 ? h->aux[l] : s;
             x.ws = carve_vit(h, h->arena + (size_t)l * lane_bytes, x.Bc, split);
+            if (lanes > 1 && h->cls_side_stream && !h->capture && x.Bc >= h->lane_min_tiles) {
+                if (!h->aux_cls[l]) HIPCHK(h, hipStreamCreateWithFlags(&h->aux_cls[l], hipStreamNonBlocking));
+                for (int e = 0; e < 3; ++e) if (!h->ev_cls[l][e]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_cls[l][e], hipEventDisableTiming));
+                if (!h->cls_splitk[l]) HIPCHK(h, hipMalloc(&h->cls_splitk[l], SKINNY_WS_BYTES));
+                x.cs = h->aux_cls[l]; x.cs_splitk = h->cls_splitk[l];
+                for (int e = 0; e < 3; ++e) x.ce[e] = h->ev_cls[l][e];
+            }
         }
         const bool skew = nl > 1 && h->lane_skew > 0;
         for (int l = 0; l < nl; ++l) {
@@ -1222,6 +1255,11 @@ int keep_destroy(keep_handle* h) {
     if (h->cls_buf) hipFree(h->cls_buf);
     if (h->err_flag) hipFree(h->err_flag);
     for (int l = 0; l < 4; ++l) { if (h->aux[l]) hipStreamDestroy(h->aux[l]); if (h->ev_join[l]) hipEventDestroy(h->ev_join[l]); }
+    for (int l = 0; l < 4; ++l) {
+        if (h->aux_cls[l]) hipStreamDestroy(h->aux_cls[l]);
+        for (int e = 0; e < 3; ++e) if (h->ev_cls[l][e]) hipEventDestroy(h->ev_cls[l][e]);
+        if (h->cls_splitk[l]) (void)hipFree(h->cls_splitk[l]);
+    }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     delete h;
     return KEEP_OK;
@@ -1299,6 +1337,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "max_prompts") { if (v < 1) return h->fail(KEEP_EINVAL, "max_prompts < 1"); h->max_prompts = v; }
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; if (h->bias_ready && h->cal_cls_tail != h->cls_tail) h->bias_ready = false; }   // (the mean-input biases of the last block were averaged under the other setting: recalibrate)
     else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
+    else if (n == "cls_side_stream") { h->cls_side_stream = v ? 1 : 0; }
     else if (n == "patch_split") { h->patch_split = v ? 1 : 0; }
     else if (n == "bias_correction") { h->bias_correction = v ? 1 : 0; }
     else if (n == "impl2128_mask") { if (v < 0 || v > 15) return h->fail(KEEP_EINVAL, "impl2128_mask must be 0..15"); h->impl2128_mask = v; }
@@ -1362,6 +1401,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "proj_impl") return h->proj_impl;
     if (n == "impl2128_mask") return h->impl2128_mask;
     if (n == "cls_qkv") return h->cls_qkv;
+    if (n == "cls_side_stream") return h->cls_side_stream;
     if (n == "patch_split") return h->patch_split;
     if (n == "bias_correction") return h->bias_correction;
     if (n == "bias_ready") return h->bias_ready ? 1 : 0;

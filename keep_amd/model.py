@@ -642,12 +642,12 @@ class KEEPModel:
                     if consider(prefix_plan(depth, full, mlp)):
                         break
             else:
-                # the shares only rank the knobs: an eighth of the probe (at least 16 tiles of every group) is enough, and 8 x faster
-                sel = torch.cat([idx[:max(16, int(idx.numel()) // 8)] for _, idx in members])
+                # the shares only rank the knobs: a sixteenth of the probe (at least 16 tiles of every group) is enough
+                sel = torch.cat([idx[:max(16, int(idx.numel()) // 16)] for _, idx in members])
                 sh_members = []
                 at = 0
                 for name, idx in members:
-                    k = min(max(16, int(idx.numel()) // 8), int(idx.numel()))
+                    k = min(max(16, int(idx.numel()) // 16), int(idx.numel()))
                     sh_members.append((name, torch.arange(at, at + k, device=dev)))
                     at += k
                 shares = self._measure_shares(tiles[sel], ref_f[sel], depth, sh_members)
