@@ -115,6 +115,8 @@ struct GemmParams {
     const float* ls;                      // [N]   (EPI_RESID_LS)
     const float* pos;                     // [197][N] (EPI_PATCH)
     float* resid;                         // fp32 [M'][N]
+    float* resid_copy; int64_t resid_copy_ld;   // nullable (small-M reduce, EPI_RESID_LS only): row m of the updated residual is ALSO stored at resid_copy + m * resid_copy_ld
+                                          // (the CLS-row chain writes its rows back into the token stream from its last reduce: no scatter launch)
     float* out_f32;                       // EPI_RESID_F32
     f16* out_hi; f16* out_lo;             // fp16 outputs (lo optional)
     int out_kt;                           // > 0: fp16 output in blk layout with KT = out_kt (= N/32); 0: row-major [M][N]
@@ -136,6 +138,7 @@ struct GemmParams {
 };
 
 int launch_gemm_f16(const GemmParams& p, int epi, hipStream_t s);             // blk-layout operands (product path); returns GEMM_DID_LN or 0
+constexpr int GEMM_NO_RESID_COPY = 2;   // launch_gemm_f16: GemmParams.resid_copy was NOT honoured (the call took a kernel without that epilogue: the caller scatters the rows)
 constexpr int GEMM_DID_LN = 1;
 // split-K scratch: 30 MiB cover every small-M shape (M <= SKINNY_MAX_M: <= 768 + 1024 partial tiles of 32 x 128 fp32);
 // the mid-size path (256x256 tiles x K slices when a GEMM has fewer tiles than CUs) needs <= 448 tiles of 256 KiB

@@ -188,6 +188,7 @@ struct keep_handle {
     // cross-queue dependency is a barrier packet the next persistent GEMM sits behind.  The premise was wrong too: the kernel times of a step add up to
     // 37.8 ms on one stream and the two-lane step takes 37.7 -- the lanes already pack the GPU back to back; what the chains cost is their own latency.
     int cls_side_stream = 0;
+    int cls_chain_early = 1;     // 2: a chain that starts with the CLS-row proj is issued even before the plain proj; 1: the chain (own stream) is issued before the block's LayerNorm-2 and scattered behind its fc2; 0: all of it behind fc2, last reduce writes the rows back
     hipStream_t aux_cls[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_cls[4][3] = {};
     float* cls_splitk[4] = {nullptr, nullptr, nullptr, nullptr};     // the chain's own K-slice scratch (the lane's is in use by its main stream)
@@ -463,6 +464,7 @@ struct VitLane {
     hipEvent_t skew_ev = nullptr; int skew_stage = 0;     // recorded after stage `skew_stage` of block 0 (lane_skew)
     bool xn_ready = false;                                // the previous block's fc2 already wrote this block's LayerNorm-1 output
     hipStream_t cs = nullptr; hipEvent_t ce[3] = {nullptr, nullptr, nullptr}; float* cs_splitk = nullptr;      // side stream of the CLS-row chain (nullable)
+    bool c_resid_live = false;                            // ws.c_resid holds the CLS rows of ws.resid as they are NOW (left there by the previous block's CLS-row chain): no gather
 };
 
 int vit_begin(keep_handle* h, VitLane& L) {
@@ -586,12 +588,12 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     ln.x = resid; ln.rows = Mr; ln.out_hi = xn_hi; ln.out_lo = mlp_lo ? xn_lo : nullptr;
     ln.out_q = mlp_q ? ws.xn_q : nullptr; ln.out_sc = mlp_q ? ws.xn_sc : nullptr; ln.out_q_hi_only = mlp == KEEP_MLP_COMP_W;
     ln.gamma = b.n2w; ln.beta = b.n2b;
-    if (proj_cls) {             // the CLS rows' residual as it enters proj (the plain proj below updates these rows too; the split result replaces that)
+    if (proj_cls && !L.c_resid_live) {      // the CLS rows' residual as it enters proj (the plain proj below updates these rows too; the split result replaces that)
         Scope sc(h, T_VIT_TAIL, s);
         launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
     }
-    int did;
-    {
+    int did = 0;
+    auto main_proj = [&]() -> int {
         const int tag = cls_only ? T_VIT_TAIL : sp ? T_VIT_PROJ_X : T_VIT_PROJ;
         Scope sc(h, tag, s);
         capture(1, att_hi, Mr, D);
@@ -600,24 +602,26 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (!mlp_q) offer_ln(p, ln);                 // the fused LayerNorm of the small-M path does not write fp4 planes
         did = run_gemm(h, tag, p, EPI_RESID_LS, s, ws.splitk);
         if (did < 0) return h->fail(KEEP_EUNSUPPORTED, "proj GEMM launch failed");
-    }
+        return KEEP_OK;
+    };
+    // cls_chain_early = 2: a chain that starts with the CLS-row proj needs nothing of the plain proj (its residual is the one in FRONT of it): issued before it
+    const bool chain_first = proj_cls && mlp_cls && h->cls_chain_early == 2 && L.cs == nullptr;
+    if (!chain_first) { const int rcp = main_proj(); if (rcp) return rcp; }
     mark(3);
     bool cls_ln_done = false;   // LayerNorm-2 of the compact CLS rows already written (hi + lo) by the CLS-row proj's epilogue
-    // the chain's stream: the lane's side stream when the block ends with the CLS-row MLP (whose scatter is the join), else the lane's own
+    // The CLS-row chain of this block (KEEP_ATTN_PROJ_CLS and / or KEEP_MLP_CLS) on the compact [Bc, D] rows.  Its stream: the lane's own -- then the whole chain is
+    // issued BEHIND the plain fc2, and its last reduce writes the rows straight back into the token stream -- or the lane's side stream ("cls_side_stream", off:
+    // measured negative), forked here and joined by a scatter behind the plain fc2.
     const bool side = mlp_cls && L.cs != nullptr;
     hipStream_t cs = side ? L.cs : s;
     float* c_splitk = side ? L.cs_splitk : ws.splitk;
-    if (mlp_cls && !proj_cls) { // the CLS rows' residual as it enters the MLP (the plain fc2 below updates these rows too; the split result replaces that)
+    if (mlp_cls && !proj_cls) { // the CLS rows' residual as it enters the MLP, i.e. BEHIND this block's proj (a live compact copy is the residual in front of it): always gathered
         Scope sc(h, T_VIT_TAIL, s);
         launch_gather_rows_f32(ws.resid, (int64_t)197 * D, ws.c_resid, Bc, D, s);
     }
-    if (side) {                 // fork: everything the chain reads (the gathered residual, the CLS rows' attention output) is queued on the lane's stream before this point
-        if (hipEventRecord(L.ce[0], s) != hipSuccess || hipStreamWaitEvent(cs, L.ce[0], 0) != hipSuccess) return h->fail(KEEP_EHIP, "CLS-row chain: fork failed");
-    }
-    if (proj_cls) {
+    auto cls_proj = [&]() -> int {
         // [Bc, D] x W_proj^T as a split product on the small-M kernels: the CLS rows' attention output from the fp32 accumulators (hi + lo) against W hi + lo,
-        // + LayerScale + the residual gathered above.  With KEEP_MLP_CLS in the same block the chain simply continues on the compact rows (its LayerNorm-2 is
-        // fused into this GEMM's reduce, its final scatter writes the rows back); otherwise the rows are written back here, before LayerNorm-2 reads them.
+        // + LayerScale + the residual.  With KEEP_MLP_CLS in the same block the chain continues on the compact rows (its LayerNorm-2 is fused into this GEMM's reduce)
         Scope sc(h, T_VIT_TAIL, cs);
         GemmParams r = gemm_params(h, ws.c_att_hi, ws.c_att_lo, b.proj, Bc, true, b.proj_b);
         r.ls = b.ls1; r.resid = ws.c_resid;
@@ -631,12 +635,11 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         const int rc = run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, cs, c_splitk);
         if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row proj GEMM launch failed");
         cls_ln_done = mlp_cls && (rc & GEMM_DID_LN);
-        if (!mlp_cls) launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
-    }
-    if (mlp_cls) {
-        // The CLS row of every tile once more, as split products on the small-M kernels: LayerNorm-2 -> fc1 + GELU -> fc2 + LayerScale + residual on the
-        // compact [Bc, D] rows (gathered after proj, or left there by the CLS-row proj), then written over the rows the plain fc2 produced.  0.5 % of the
-        // rows; the feature is pooled from them.  On the side stream this runs under the lane's own LayerNorm-2 / fc1 / fc2 below.
+        return KEEP_OK;
+    };
+    auto cls_mlp = [&](bool write_back) -> int {
+        // LayerNorm-2 -> fc1 + GELU -> fc2 + LayerScale + residual as split products on the compact rows; `write_back`: the last reduce also stores the rows into the
+        // token stream (they replace what the plain fc2 wrote there: the caller orders this behind it).  0.5 % of the rows; the feature is pooled from them.
         Scope sc(h, T_VIT_TAIL, cs);
         LnParams cl{};
         cl.tune = &h->tune;
@@ -648,7 +651,24 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (run_gemm(h, T_VIT_TAIL, p, EPI_GELU_F16, cs, c_splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc1 GEMM launch failed");
         GemmParams r = gemm_params(h, ws.c_mlp_hi, ws.c_mlp_lo, b.fc2, Bc, true, b.fc2_b);
         r.ls = b.ls2; r.resid = ws.c_resid;
-        if (run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, cs, c_splitk) < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc2 GEMM launch failed");
+        if (write_back) { r.resid_copy = ws.resid; r.resid_copy_ld = (int64_t)197 * D; }
+        const int rc = run_gemm(h, T_VIT_TAIL, r, EPI_RESID_LS, cs, c_splitk);
+        if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "CLS-row fc2 GEMM launch failed");
+        if (write_back && (rc & GEMM_NO_RESID_COPY)) launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, cs);      // (kernel-selection experiments only)
+        return KEEP_OK;
+    };
+    const bool early = mlp_cls && !side && h->cls_chain_early;      // in the lane's own stream, but issued HERE (before LayerNorm-2; = 2: even before the plain proj) and scattered behind the plain fc2
+    if (side || early) {        // fork: everything the chain reads (the gathered residual, the CLS rows' attention output) is queued on the lane's stream before this point
+        if (side && (hipEventRecord(L.ce[0], s) != hipSuccess || hipStreamWaitEvent(cs, L.ce[0], 0) != hipSuccess)) return h->fail(KEEP_EHIP, "CLS-row chain: fork failed");
+        int rc2 = proj_cls ? cls_proj() : KEEP_OK;
+        if (!rc2) rc2 = cls_mlp(false);
+        if (rc2) return rc2;
+        if (chain_first && (rc2 = main_proj())) return rc2;
+    } else if (proj_cls && !mlp_cls) {      // no CLS-row MLP behind it: the rows go back before LayerNorm-2 reads them
+        const int rc2 = cls_proj();
+        if (rc2) return rc2;
+        Scope sc(h, T_VIT_TAIL, s);
+        launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
     }
     if (!(did & GEMM_DID_LN) && !skip_ln) {
         Scope sc(h, T_VIT_LN, s);
@@ -687,12 +707,20 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
         if (rc < 0) return h->fail(KEEP_EUNSUPPORTED, "fc2 GEMM launch failed");
         L.xn_ready = (rc & GEMM_DID_LN) != 0;
     }
-    if (mlp_cls) {              // the join: the chain's rows replace what the plain fc2 wrote (ordered after it), and the lane goes on behind the scatter
+    if (mlp_cls && side) {      // the join: the chain's rows replace what the plain fc2 wrote (ordered after it), and the lane goes on behind the scatter
         Scope sc(h, T_VIT_TAIL, cs);
-        if (side && (hipEventRecord(L.ce[1], s) != hipSuccess || hipStreamWaitEvent(cs, L.ce[1], 0) != hipSuccess)) return h->fail(KEEP_EHIP, "CLS-row chain: join failed");
+        if (hipEventRecord(L.ce[1], s) != hipSuccess || hipStreamWaitEvent(cs, L.ce[1], 0) != hipSuccess) return h->fail(KEEP_EHIP, "CLS-row chain: join failed");
         launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, cs);
-        if (side && (hipEventRecord(L.ce[2], cs) != hipSuccess || hipStreamWaitEvent(s, L.ce[2], 0) != hipSuccess)) return h->fail(KEEP_EHIP, "CLS-row chain: join failed");
+        if (hipEventRecord(L.ce[2], cs) != hipSuccess || hipStreamWaitEvent(s, L.ce[2], 0) != hipSuccess) return h->fail(KEEP_EHIP, "CLS-row chain: join failed");
+    } else if (early) {
+        Scope sc(h, T_VIT_TAIL, s);
+        launch_scatter_rows_f32(ws.c_resid, ws.resid, (int64_t)197 * D, Bc, D, s);
+    } else if (mlp_cls) {       // in the lane's own stream: the whole chain behind the plain fc2, the rows written back by its last reduce
+        int rc2 = proj_cls ? cls_proj() : KEEP_OK;
+        if (!rc2) rc2 = cls_mlp(true);
+        if (rc2) return rc2;
     }
+    L.c_resid_live = mlp_cls;   // (any other block's proj / fc2 moved the CLS rows of the token stream on without the compact copy)
     mark(5);
     return KEEP_OK;
 }
@@ -1338,6 +1366,7 @@ int keep_set_option(keep_handle* h, const char* name, double value) {
     else if (n == "cls_tail") { h->cls_tail = v ? 1 : 0; if (h->bias_ready && h->cal_cls_tail != h->cls_tail) h->bias_ready = false; }   // (the mean-input biases of the last block were averaged under the other setting: recalibrate)
     else if (n == "cls_qkv") { h->cls_qkv = v ? 1 : 0; }
     else if (n == "cls_side_stream") { h->cls_side_stream = v ? 1 : 0; }
+    else if (n == "cls_chain_early") { if (v < 0 || v > 2) return h->fail(KEEP_EINVAL, "cls_chain_early must be 0..2"); h->cls_chain_early = v; }
     else if (n == "patch_split") { h->patch_split = v ? 1 : 0; }
     else if (n == "bias_correction") { h->bias_correction = v ? 1 : 0; }
     else if (n == "impl2128_mask") { if (v < 0 || v > 15) return h->fail(KEEP_EINVAL, "impl2128_mask must be 0..15"); h->impl2128_mask = v; }
@@ -1402,6 +1431,7 @@ double keep_get_option(keep_handle* h, const char* name) {
     if (n == "impl2128_mask") return h->impl2128_mask;
     if (n == "cls_qkv") return h->cls_qkv;
     if (n == "cls_side_stream") return h->cls_side_stream;
+    if (n == "cls_chain_early") return h->cls_chain_early;
     if (n == "patch_split") return h->patch_split;
     if (n == "bias_correction") return h->bias_correction;
     if (n == "bias_ready") return h->bias_ready ? 1 : 0;

@@ -48,6 +48,7 @@ int launch_gemm_f16(const GemmParams& p_in, int epi, hipStream_t s) {
         }
     }
     if ((impl != 128 && impl != 256) || (impl == 256 && p.N % 256)) impl = (p.N % 256 == 0) ? 256 : 128;
+    if (p.resid_copy) return launch_gemm_f16_v2(p, epi, impl, s) == 0 ? GEMM_NO_RESID_COPY : -1;      // (only the split-K reduce kernels store the second copy)
     return launch_gemm_f16_v2(p, epi, impl, s) == 0 ? 0 : -1;      // (-1: shape not covered or the LDS opt-in was refused -- the callers report it)
 }
 

@@ -189,6 +189,7 @@ void gemm_skinny_reduce_kernel(GemmParams p, const float* __restrict__ part, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] += __fmul_rn(g[e], v[e]);     // LayerScale product rounded on its own, as the 256x256 kernel does: torch's x + gamma * y on every path
         *reinterpret_cast<f32x4*>(p.resid + o) = r;
+        if (p.resid_copy) *reinterpret_cast<f32x4*>(p.resid_copy + orow * p.resid_copy_ld + n) = r;
     } else if (EPI == EPI_PATCH) {
         const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
 #pragma unroll

@@ -42,7 +42,7 @@ CONFIDENCE = 0.99
 PROBE_RMS_MARGIN = 1.02
 # Milliseconds a knob adds to a 256-tile encode step on an MI355X (two lanes; tools/precision_budget.py measures them, profiles/r05_precision_budget.md):
 # what the greedy of budget="measured" divides a knob's variance share by.  Only the RATIOS matter.
-KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "attn_proj_cls": 0.03, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.10}
+KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "attn_proj_cls": 0.012, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.07}
 # Share of a site's rounding variance that survives a treatment when it is not measured on the loaded weights (same tool, bench weights): both
 # MX-fp4 correction terms remove ~96 % of an MLP's share, the W_lo term alone 40-55 %; a compensated qkv inside a split attention side leaves 1-2 %
 MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_CLS: 0.1, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}

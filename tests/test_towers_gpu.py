@@ -614,7 +614,7 @@ def test_config3_fixture_first_chunk(golden_dir):
         assert dc.max() < tol(precision, 5e-6)
         assert torch.equal(clab.cpu().long(), ref_lab)
         if precision == "comp":
-            assert 0 < m.last_rechecked < chunk // 4
+            assert 0 <= m.last_rechecked < chunk // 4                # (with the margin scaled by this bank's prompt distances the first chunk may hold no tile to look at twice)
             lm = m.get_option("label_margin")                       # set by calibrate(): sqrt 2 x the predicted worst cosine error (<= 1.42e-4), not a fixed 2.5e-4
             assert 5e-5 < lm <= 2 ** 0.5 * COS_TOL * 1.001 and lm == pytest.approx(m.calibration["label_margin"], rel=1e-3)
             # classify scales the calibrated per-unit margin by THIS bank's largest prompt distance (<= 2; sqrt 2 is the engine's own default)
