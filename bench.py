@@ -48,7 +48,7 @@ PEAK_F16_TFLOPS = 2516.6     # 256 CU x 4096 FLOP/clk x 2.4 GHz, dense (BASELINE
 PEAK_HBM_GBS = 8000.0
 # The kernel that takes the largest share of a step: gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,0,true> -- the persistent 256x256 GEMM with the
 # LayerScale + fp32 residual read-modify-write epilogue, launched for fc2 ([B*197,4096] x [4096,1024]) of every block that runs it as a single fp16
-# pass (27 % of the step: profiles/r05_per_kernel_table.md; proj has its own kernel since round 5).  The engine times those launches under this tag.
+# pass (26-27 % of the step: profiles/r06_per_kernel_table.md; proj has its own kernel since round 5).  The engine times those launches under this tag.
 DOMINANT_TAGS = ("vit.fc2",)
 DOMINANT_KERNEL = "keepk::gemm_f16_v2_kernel<256,2,4,4,EPI_RESID_LS,0,true> (persistent; the vit.fc2 launches)"
 BERT_FLOPS_PER_PROMPT_256 = 45_903_642_624
@@ -748,7 +748,7 @@ def main():
         # HBM-side traffic of the dominant kernel: PMC counters need rocprofv3 around the process (separate FETCH_SIZE / WRITE_SIZE passes, the guide's
         # gfx950 correction), so it is read from the committed summary of tools/refresh_profiles.sh and labelled with the library build it was taken on
         traffic, traffic_src, traffic_tiles = None, None, None
-        for rnd in ("r05", "r04", "r03"):
+        for rnd in ("r06", "r05", "r04", "r03"):
             tpath = os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
@@ -769,7 +769,7 @@ def main():
         roofline = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", **rate(dom_ms, dom_n, dom_fl),
                     "traffic": traffic, "traffic_tiles_per_launch": traffic_tiles, "flops_tiles_per_launch": B, "traffic_source": traffic_src,
                     "timing": "single_stream_pass: HIP events around every launch of this kernel, on the stream it is launched on, 3 encode calls of 256 tiles with one "
-                              "internal stream (nothing else on the GPU): a kernel figure, comparable with profiles/r05_rocprofv3_kernel_stats_single_stream.csv",
+                              "internal stream (nothing else on the GPU): a kernel figure, comparable with profiles/r06_rocprofv3_kernel_stats_single_stream.csv",
                     "share_of_single_stream_step": round(dom_ms / max(sum(v[0] for v in single.values()), 1e-9), 4) if single else None,
                     "by_operator": {t: rate(*single[t]) for t in DOMINANT_TAGS if t in single},
                     "in_timed_region_two_lane": {**rate(*(sum(in_region[t][i] for t in DOMINANT_TAGS) for i in range(3))),

@@ -24,15 +24,16 @@ KERNELS = [
     (r"gemm_f16_v2_kernel<128, 2, 2, 3, 2, 0, false>", "proj GEMM (256x128 tiles, two workgroups per CU, LayerScale + fp32 residual RMW)", G(1024, 1024), None, "mfma"),
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 1, 2, false>", "fc1 GEMM + MX-fp4 correction phase (both terms)", G(4096, 1024), None, "mfma"),
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, 2, false>", "fc2 GEMM + MX-fp4 correction phase (both terms)", G(1024, 4096), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, 2, false>", "qkv GEMM + MX-fp4 correction phase (block 0)", G(3072, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, 2, false>", "qkv GEMM + MX-fp4 correction phase (the split-attention blocks)", G(3072, 1024), None, "mfma"),
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 0, 0, false>", "qkv GEMM, split product (3 fp16 passes)", G(3072, 1024), None, "mfma"),
-    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, 0, false>", "proj GEMM, split product (block 0)", G(1024, 1024), None, "mfma"),
+    (r"gemm_f16_v2_kernel<256, 2, 4, 4, 2, 0, false>", "proj GEMM, split product (the split-attention blocks)", G(1024, 1024), None, "mfma"),
     (r"gemm_f16_v2_kernel<256, 2, 4, 4, 3, 0, false>", "patch-embed GEMM, split product", 2.0 * 256 * 196 * 768 * 1024, None, "mfma"),
     (r"attention_pers_kernel<13>", "attention (197 tokens, 16 heads; persistent, next pair's K / V staged under the compute)", 4.0 * 256 * 16 * 197 * 197 * 64, 2.0 * M * 4096, "mfma"),
     (r"attention_kernel<13, false, 8>", "attention, last block (CLS query only)", None, None, "mfma"),
-    (r"attention_kernel<13, true, 4>", "attention, split product (block 0)", 4.0 * 256 * 16 * 197 * 197 * 64, 4.0 * M * 4096, "mfma"),
+    (r"attention_kernel<13, true, 4>", "attention, split product (the split-attention blocks)", 4.0 * 256 * 16 * 197 * 197 * 64, 4.0 * M * 4096, "mfma"),
     (r"layernorm_blk_kernel<4, 8>", "LayerNorm (fp32 in, fp16 K-blocked out; the average includes the 256-row launches of the CLS-row path)", None, None, "hbm"),
-    (r"gemm_skinny_partial_kernel", "CLS rows: small-M GEMM, K-sliced partial products (fc1 / fc2 of the CLS-row path, last block's tail)", None, None, "mfma"),
+    (r"gemm_skinny_partial_wide_kernel", "CLS rows: small-M GEMM, 128x128 tiles, K-sliced partial products (proj / fc1 / fc2 of the CLS-row chain, last block's tail)", None, None, "mfma"),
+    (r"gemm_skinny_partial_kernel", "small-M GEMM, 32x128 tiles (calls of < 64 rows)", None, None, "mfma"),
     (r"gemm_skinny_reduce", "CLS rows: partial-sum reduce + epilogue", None, None, "hbm"),
     (r"im2col_kernel", "im2col (+ cls / pos rows)", None, 256 * 3 * 224 * 224 * 2 + 2 * 2.0 * 256 * 196 * 768, "hbm"),
 ]

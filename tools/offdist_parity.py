@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--probe", default="mixture", choices=["mixture", "gaussian"], help="what the load-time calibration probes (KEEPModel.calibration_probe)")
     ap.add_argument("--bias-probe", default=None, choices=["mixture", "gaussian", "off"], help="what calibrate_bias probes (default: the same as --probe)")
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--only-calibrated", action="store_true", help="skip the no-compensation / all-plain yardsticks (full-size runs)")
     ap.add_argument("--out", default="gpurun_out/offdist_parity.json")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -135,8 +136,10 @@ def main():
         f_s = encode_all(model, fam, n, dev, args.seed)
         s64_s, sD_s = model.similarity(f_s, t64_s), model.similarity(f_s, tD_s)
         model.set_precision("comp")
-        for label, plan, bias in (("calibrated_plan", own, 1), ("calibrated_plan_no_bias_compensation", own, 0),
-                                  ("all_plain_fp16", [(0, 0)] * depth, 1), ("all_plain_fp16_no_bias_compensation", [(0, 0)] * depth, 0)):
+        variants = (("calibrated_plan", own, bias_was),) if args.only_calibrated else (
+            ("calibrated_plan", own, 1), ("calibrated_plan_no_bias_compensation", own, 0),
+            ("all_plain_fp16", [(0, 0)] * depth, 1), ("all_plain_fp16_no_bias_compensation", [(0, 0)] * depth, 0))
+        for label, plan, bias in variants:
             model.set_plan(plan)
             model.set_option("bias_correction", bias)
             f = encode_all(model, fam, n, dev, args.seed)
@@ -155,6 +158,12 @@ def main():
         r["seconds"] = round(time.perf_counter() - t0, 1)
         res["families"][fam] = r
         c = r["calibrated_plan"]
+        if args.only_calibrated:
+            print(f"[{fam}, {n} tiles] 64 prompts: max {c['cos_vs_64_prompts']['max_abs']:.3e} rms {c['cos_vs_64_prompts']['rms']:.3e} over {c['cos_vs_64_prompts']['over_1e-4']}; "
+                  f"264 prompts: max {c['cos_vs_264_distinct_prompts']['max_abs']:.3e} rms {c['cos_vs_264_distinct_prompts']['rms']:.3e} over {c['cos_vs_264_distinct_prompts']['over_1e-4']} "
+                  f"max/rms {c['cos_vs_264_distinct_prompts']['max_over_rms']}; isotropic rms {c['isotropic_rms']:.3e} hardest tile / rms {c['hardest_tile_over_rms']}; "
+                  f"population exceedance from this slide {c['population_exceedance_from_slide_tile_errors']:.2e}", flush=True)
+            continue
         print(f"[{fam}] calibrated: 64p max {c['cos_vs_64_prompts']['max_abs']:.3e} rms {c['cos_vs_64_prompts']['rms']:.3e} over {c['cos_vs_64_prompts']['over_1e-4']}; "
               f"exceed {c['population_exceedance_from_slide_tile_errors']:.2e} hardest/rms {c['hardest_tile_over_rms']} iso {c['isotropic_rms']:.3e}; "
               f"264p max {c['cos_vs_264_distinct_prompts']['max_abs']:.3e} rms {c['cos_vs_264_distinct_prompts']['rms']:.3e} over {c['cos_vs_264_distinct_prompts']['over_1e-4']}; "
