@@ -616,8 +616,10 @@ def main():
         rccl_ranks_seen = int(round(float(ones.item())))
         if rccl_ranks_seen != world:
             raise SystemExit(f"RCCL all-reduce saw {rccl_ranks_seen} ranks, expected {world}")
-        # every rank calibrates on its own at load: a scaling figure must not mix settings
-        from keep_amd.distributed import assert_same_setting
+        # every rank calibrates on its own at load, and the rule's verdict can sit within a rounding of its threshold: rank 0's plan (verified there, on the same
+        # weights and probe) runs on every rank -- a scaling figure must not mix settings
+        from keep_amd.distributed import adopt_rank0_plan, assert_same_setting
+        adopt_rank0_plan(model, device=dev)
         assert_same_setting([model.get_option("precision")] + [float(v) for am in model.get_plan() for v in am],
                             "precision setting (precision, per-block plan)", device=dev)
     for _ in range(args.warmup):

@@ -209,3 +209,28 @@ def assert_same_setting(values, what: str = "precision setting", device=None, gr
     if any(r != got[0] for r in got):
         raise RuntimeError(f"ranks disagree on the {what}: " + "; ".join(f"rank {i}: {r}" for i, r in enumerate(got)))
     return got
+
+
+def adopt_rank0_plan(model, device=None, group=None, src: int = 0) -> list:
+    """Every rank calibrates on its own at load, and the rule's verdict on a candidate plan can sit within a rounding of its threshold (two boxes have been
+    seen to keep plans that differ in ONE block): a multi-rank job then runs rank ``src``'s plan everywhere.  The plan is a property of the weights -- identical
+    on every rank -- and was verified on that rank against the same probe; what is broadcast is (precision, label margin figures, the per-block plan).  Returns
+    the adopted plan.  Without a process group: a no-op."""
+    plan = [tuple(int(v) for v in am) for am in model.get_plan()]
+    if not (dist.is_available() and dist.is_initialized()):
+        return plan
+    unit = getattr(model, "_label_margin_unit", None)
+    row = torch.tensor([float(model.get_option("precision")), float(model.get_option("label_margin")), float(unit or 0.0)] + [float(v) for am in plan for v in am],
+                       dtype=torch.float64, device=device)
+    dist.broadcast(row, src=src, group=group)
+    got = row.tolist()
+    new_plan = [(int(round(got[3 + 2 * i])), int(round(got[4 + 2 * i]))) for i in range(len(plan))]
+    if dist.get_rank(group) != src:
+        precision = {0: "fp16", 1: "strict", 2: "comp"}[int(round(got[0]))]
+        if int(round(model.get_option("precision"))) != int(round(got[0])):
+            model.set_precision(precision, int(model.get_option("strict_blocks")))
+        if new_plan != plan:
+            model.set_plan(new_plan)
+        model.set_option("label_margin", got[1])
+        model._label_margin_unit = got[2] or None
+    return new_plan
