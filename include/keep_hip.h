@@ -76,6 +76,8 @@ enum {
                                   /* hi + lo from the fp32 accumulators and its proj runs again as a split product (B rows): on      */
                                   /* spatially correlated tiles the proj GEMM carries ~70 % of the attention side's rounding error   */
                                   /* and the CLS row's own share of it is what reaches the pooled feature (round 6)                  */
+    , KEEP_ATTN_COMPQKV_PROJ_CLS = 5 /* KEEP_ATTN_COMPQKV and KEEP_ATTN_PROJ_CLS together: compensated qkv GEMM, plain attention, plain     */
+                                  /* proj + the CLS rows' proj again as a split product -- between "CLS-row proj" and "everything split"   */
 };
 enum {
     KEEP_MLP_PLAIN = 0,           /* fc1 / fc2: single fp16 passes                                                                  */

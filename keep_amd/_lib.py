@@ -18,7 +18,7 @@ KEEP_OK, KEEP_EINVAL, KEEP_ESTATE, KEEP_EKEY, KEEP_EHIP, KEEP_EUNSUPPORTED, KEEP
 PIX_F32, PIX_F16, PIX_BF16, PIX_U8_HWC = 0, 1, 2, 3
 SIM_RAW, SIM_ARGMAX, SIM_SOFTMAX, SIM_SOFTMAX_F16, SIM_TOP2SCORE = 0, 1, 2, 3, 4
 PREC_FP16, PREC_STRICT, PREC_COMP = 0, 1, 2
-ATTN_PLAIN, ATTN_SPLIT, ATTN_SPLIT_COMPQKV, ATTN_COMPQKV, ATTN_PROJ_CLS = 0, 1, 2, 3, 4        # keep_set_block_precision: attention side of a ViT block
+ATTN_PLAIN, ATTN_SPLIT, ATTN_SPLIT_COMPQKV, ATTN_COMPQKV, ATTN_PROJ_CLS, ATTN_COMPQKV_PROJ_CLS = 0, 1, 2, 3, 4, 5        # keep_set_block_precision: attention side of a ViT block
 MLP_PLAIN, MLP_SPLIT, MLP_COMP, MLP_COMP_W, MLP_CLS = 0, 1, 2, 3, 4          # ... and its MLP
 
 _vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float

@@ -108,7 +108,8 @@ struct keep_handle {
     // The per-block plan of KEEP_PREC_COMP (keep_set_block_precision; the four options above are prefix shorthands that rewrite it):
     //   attn_mode[i]  attention side of block i: KEEP_ATTN_PLAIN | KEEP_ATTN_SPLIT (qkv, q/k/v storage, attention, proj as split products) |
     //                 KEEP_ATTN_SPLIT_COMPQKV (the same with the qkv GEMM as a compensated product) | KEEP_ATTN_COMPQKV (compensated qkv only) |
-    //                 KEEP_ATTN_PROJ_CLS (plain for every row + the CLS rows' proj again as a split product on their fp32-grade attention output)
+    //                 KEEP_ATTN_PROJ_CLS (plain for every row + the CLS rows' proj again as a split product on their fp32-grade attention output) |
+    //                 KEEP_ATTN_COMPQKV_PROJ_CLS (both of the last two)
     //   mlp_mode[i]   fc1 / fc2 of block i: KEEP_MLP_PLAIN | KEEP_MLP_SPLIT | KEEP_MLP_COMP (both MX-fp4 correction terms) | KEEP_MLP_COMP_W (the W_lo term only) |
     //                 KEEP_MLP_CLS (plain for every row + the CLS rows again as split products)
     // Which block gets what is a measured, per-checkpoint decision (tools/precision_budget.py, KEEPModel.calibrate).
@@ -223,12 +224,12 @@ struct keep_handle {
     bool vit_attn_split(int i, int lane_tiles = 1 << 20) const {
         if (precision == KEEP_PREC_STRICT || i < strict_blocks) return true;
         const int a = plan_attn(i);
-        return a == KEEP_ATTN_SPLIT || a == KEEP_ATTN_SPLIT_COMPQKV || (a == KEEP_ATTN_COMPQKV && !(lane_tiles >= comp_min_tiles && vit_has_q));
+        return a == KEEP_ATTN_SPLIT || a == KEEP_ATTN_SPLIT_COMPQKV || ((a == KEEP_ATTN_COMPQKV || a == KEEP_ATTN_COMPQKV_PROJ_CLS) && !(lane_tiles >= comp_min_tiles && vit_has_q));
     }
     bool vit_qkv_comp(int i, int lane_tiles) const {
         if (precision != KEEP_PREC_COMP || i < strict_blocks || !(lane_tiles >= comp_min_tiles && vit_has_q)) return false;
         const int a = plan_attn(i);
-        return a == KEEP_ATTN_SPLIT_COMPQKV || a == KEEP_ATTN_COMPQKV;
+        return a == KEEP_ATTN_SPLIT_COMPQKV || a == KEEP_ATTN_COMPQKV || a == KEEP_ATTN_COMPQKV_PROJ_CLS;
     }
     // fc1 / fc2 of block i: 0 plain | 1 split (three fp16 passes) | 2 compensated (both MX-fp4 terms) | 3 compensated, W_lo term only | 4 plain + CLS rows split
     // (lane_tiles == 0: the last block's CLS-rows-only tail, which is the "CLS rows as split products" half on its own)
@@ -248,7 +249,7 @@ struct keep_handle {
     bool any_comp() const {
         if (precision != KEEP_PREC_COMP || !vit_has_q) return false;
         for (int i = 0; i < MAX_BLOCKS && i < (vit_depth ? vit_depth : MAX_BLOCKS); ++i)
-            if (mlp_mode[i] == KEEP_MLP_COMP || mlp_mode[i] == KEEP_MLP_COMP_W || attn_mode[i] == KEEP_ATTN_SPLIT_COMPQKV || attn_mode[i] == KEEP_ATTN_COMPQKV) return true;
+            if (mlp_mode[i] == KEEP_MLP_COMP || mlp_mode[i] == KEEP_MLP_COMP_W || attn_mode[i] == KEEP_ATTN_SPLIT_COMPQKV || attn_mode[i] == KEEP_ATTN_COMPQKV || attn_mode[i] == KEEP_ATTN_COMPQKV_PROJ_CLS) return true;
         return false;
     }
 
@@ -514,7 +515,7 @@ int vit_layer(keep_handle* h, VitLane& L, int i) {
     const bool mlp_cls = mlp == KEEP_MLP_CLS;                          // every row plain, then the CLS rows again as split products (below)
     const bool mlp_plain = mlp == KEEP_MLP_PLAIN || mlp_cls;
     // KEEP_ATTN_PROJ_CLS: every row plain; the attention kernel also writes the CLS rows' output hi + lo (compact), and their proj runs again as a split product
-    const bool proj_cls = !sp && !cls_only && h->plan_attn(i) == KEEP_ATTN_PROJ_CLS && i >= h->strict_blocks;
+    const bool proj_cls = !sp && !cls_only && (h->plan_attn(i) == KEEP_ATTN_PROJ_CLS || h->plan_attn(i) == KEEP_ATTN_COMPQKV_PROJ_CLS) && i >= h->strict_blocks;
 #ifdef KEEP_DIAGNOSTICS
     const bool skip_ln = h->dbg_skip_ln == 1 && h->dbg_calls > 3;
 #else
@@ -1441,7 +1442,7 @@ double keep_get_option(keep_handle* h, const char* name) {
 int keep_set_block_precision(keep_handle* h, int block, int attn_mode, int mlp_mode) {
     if (!h) return KEEP_EINVAL;
     if (block < 0 || block >= keep_handle::MAX_BLOCKS) return h->fail(KEEP_EINVAL, "block %d outside 0..%d", block, keep_handle::MAX_BLOCKS - 1);
-    if (attn_mode > KEEP_ATTN_PROJ_CLS || mlp_mode > KEEP_MLP_CLS) return h->fail(KEEP_EINVAL, "attn_mode %d (0..4) / mlp_mode %d (0..4); negative = leave", attn_mode, mlp_mode);
+    if (attn_mode > KEEP_ATTN_COMPQKV_PROJ_CLS || mlp_mode > KEEP_MLP_CLS) return h->fail(KEEP_EINVAL, "attn_mode %d (0..5) / mlp_mode %d (0..4); negative = leave", attn_mode, mlp_mode);
     ++h->opt_epoch;               // captured graphs bake the plan in
     if (attn_mode >= 0) h->attn_mode[block] = (unsigned char)attn_mode;
     if (mlp_mode >= 0) h->mlp_mode[block] = (unsigned char)mlp_mode;

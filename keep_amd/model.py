@@ -42,11 +42,11 @@ CONFIDENCE = 0.99
 PROBE_RMS_MARGIN = 1.02
 # Milliseconds a knob adds to a 256-tile encode step on an MI355X (two lanes; tools/precision_budget.py measures them, profiles/r05_precision_budget.md):
 # what the greedy of budget="measured" divides a knob's variance share by.  Only the RATIOS matter.
-KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "attn_proj_cls": 0.012, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.07}
+KNOB_COST_MS = {"attn_split": 0.92, "attn_split_compqkv": 0.56, "attn_compqkv": 0.22, "attn_proj_cls": 0.012, "attn_compqkv_proj_cls": 0.18, "mlp_comp": 0.52, "mlp_comp_w": 0.29, "mlp_cls": 0.07}
 # Share of a site's rounding variance that survives a treatment when it is not measured on the loaded weights (same tool, bench weights): both
 # MX-fp4 correction terms remove ~96 % of an MLP's share, the W_lo term alone 40-55 %; a compensated qkv inside a split attention side leaves 1-2 %
 MLP_RESIDUAL = {_lib.MLP_PLAIN: 1.0, _lib.MLP_CLS: 0.1, _lib.MLP_COMP_W: 0.55, _lib.MLP_COMP: 0.04, _lib.MLP_SPLIT: 0.0}
-ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_PROJ_CLS: 0.55, _lib.ATTN_SPLIT_COMPQKV: 0.015, _lib.ATTN_SPLIT: 0.0}
+ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_PROJ_CLS: 0.55, _lib.ATTN_COMPQKV_PROJ_CLS: 0.25, _lib.ATTN_SPLIT_COMPQKV: 0.015, _lib.ATTN_SPLIT: 0.0}
 # The treatments the greedy of budget="measured" may use.  Measured on the bench weights (profiles/r05_precision_budget.md): the W_lo-only MLP form
 # removes ~45 % of a block's MLP share for 57 % of the cost of both terms, and a compensated qkv alone ~35 % of an attention side's share at 1 ms per
 # percent of variance against 0.45 for MLP blocks -- neither ever wins a greedy step, so they are off by default (``knobs=`` switches them on).
@@ -56,7 +56,7 @@ ATTN_RESIDUAL = {_lib.ATTN_PLAIN: 1.0, _lib.ATTN_COMPQKV: 0.6, _lib.ATTN_PROJ_CL
 # KEEP_ATTN_PROJ_CLS (round 6) is the attention side's counterpart: on spatially correlated tiles ~70 % of an attention side's rounding error is its proj
 # GEMM's (tools/attn_site_study.py), and redoing the CLS row's proj as a split product on its fp32-grade attention output removes what a full CLS-row
 # treatment of the attention side would -- for one more small GEMM in the CLS-row chain (measured per block and tile group, like KEEP_MLP_CLS).
-DEFAULT_KNOBS = {"attn": (_lib.ATTN_PROJ_CLS, _lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_CLS, _lib.MLP_COMP)}
+DEFAULT_KNOBS = {"attn": (_lib.ATTN_PROJ_CLS, _lib.ATTN_COMPQKV_PROJ_CLS, _lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_SPLIT), "mlp": (_lib.MLP_CLS, _lib.MLP_COMP)}
 
 Plan = List[Tuple[int, int]]
 
@@ -411,8 +411,8 @@ class KEEPModel:
         """The per-block plan of the 'comp' mode: ``plan[i] = (attention-side mode, MLP mode)`` of ViT block i (``_lib.ATTN_*`` / ``_lib.MLP_*``,
         = KEEP_ATTN_* / KEEP_MLP_* of include/keep_hip.h).  Blocks beyond ``len(plan)`` run plain fp16 passes."""
         plan = [(int(a), int(m)) for a, m in plan]
-        if any(not (0 <= a <= 4 and 0 <= m <= 4) for a, m in plan) or len(plan) > 64:
-            raise ValueError("a plan holds at most 64 (attn_mode 0..4, mlp_mode 0..4) pairs")
+        if any(not (0 <= a <= 5 and 0 <= m <= 4) for a, m in plan) or len(plan) > 64:
+            raise ValueError("a plan holds at most 64 (attn_mode 0..5, mlp_mode 0..4) pairs")
         pre = plan_prefix(plan)
         for k in self._PLAN_SHORTHANDS:
             self._options.pop(k, None)
@@ -764,8 +764,8 @@ class KEEPModel:
         for mode in (_lib.MLP_COMP, _lib.MLP_COMP_W):
             fr = [ratio(minus_floor(var_of(i, (_lib.ATTN_SPLIT, mode))), mlp[i]) for i in sorted({0, depth // 2})]
             res_m[mode] = [sum(f[g] for f in fr) / len(fr) for g in range(G)]
-        for mode in (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_COMPQKV):
-            fr = [ratio(minus_floor(var_of(i, (mode, _lib.MLP_SPLIT))), attn[i]) for i in sorted({0, depth // 2})]
+        for mode in (_lib.ATTN_SPLIT_COMPQKV, _lib.ATTN_COMPQKV, _lib.ATTN_COMPQKV_PROJ_CLS):
+            fr = [ratio(minus_floor(var_of(i, (mode, _lib.MLP_SPLIT))), attn[i]) for i in sorted({0, min(1, depth - 1), depth // 2})]
             res_a[mode] = [max(f[g] for f in fr) for g in range(G)]
         # ... and so does what the CLS-row proj leaves of an attention side (nearly all of it in block 0 of N(0,1) tiles, under half on correlated tiles)
         pcls_left = [ratio(minus_floor(var_of(i, (_lib.ATTN_PROJ_CLS, _lib.MLP_SPLIT))), attn[i]) for i in range(depth)]
@@ -800,6 +800,7 @@ class KEEPModel:
         left_m = lambda g, i, mode: (res_m[g][mode][i] if isinstance(res_m[g][mode], (list, tuple)) else res_m[g][mode])
         left_a = lambda g, i, mode: (res_a[g][mode][i] if isinstance(res_a[g][mode], (list, tuple)) else res_a[g][mode])
         cost_a = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_PROJ_CLS: KNOB_COST_MS["attn_proj_cls"], _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"],
+                  _lib.ATTN_COMPQKV_PROJ_CLS: KNOB_COST_MS["attn_compqkv_proj_cls"],
                   _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"], _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
         cost_m = {_lib.MLP_PLAIN: 0.0, _lib.MLP_CLS: KNOB_COST_MS["mlp_cls"], _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"],
                   _lib.MLP_SPLIT: 3.0 * KNOB_COST_MS["mlp_comp"]}

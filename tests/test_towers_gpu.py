@@ -880,6 +880,8 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     # share -- what it does on correlated tiles is measured in tests/test_tile_families.py)
     m.set_plan([(4, 0)] * depth); e_pc = err(m.encode_image(x)); assert m.get_plan() == [(4, 0)] * depth
     m.set_plan([(4, 4)] * depth); e_pc_cls = err(m.encode_image(x))
+    m.set_plan([(5, 4)] * depth); e_cq_pc = err(m.encode_image(x)); assert m.get_plan() == [(5, 4)] * depth          # + a compensated qkv GEMM: not worse
+    assert e_cq_pc < 1.02 * e_pc_cls
     assert torch.equal(m.encode_image(x), m.encode_image(x))
     print(f"[plans, depth {depth}] CLS rows' proj split: {e_pc:.3e}; + CLS-row MLP: {e_pc_cls:.3e}")
     assert e_split * 0.9 <= e_pc < 1.02 * e_plain and e_pc_cls < 1.02 * got["mlp plain + CLS rows split"]
@@ -898,7 +900,7 @@ def test_per_block_plan_is_what_the_prefix_options_stand_for():
     m.set_option("comp_mlp_blocks", 1)
     assert m.get_plan() == prefix_plan(depth, 0, 1) and m.get_option("plan_custom") == 0
     lib = _lib.load()
-    for bad in ((0, 5, 0), (0, 0, 5), (64, 1, 1), (-1, 1, 1)):
+    for bad in ((0, 6, 0), (0, 0, 5), (64, 1, 1), (-1, 1, 1)):
         assert lib.keep_set_block_precision(m._handle, *bad) == _lib.KEEP_EINVAL
     with pytest.raises(ValueError):
         m.set_plan([(0, 7)])
