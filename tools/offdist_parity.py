@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Does the calibrated 'comp' plan hold the 1e-4 cosine tolerance OFF the distribution its calibration probes?
 
-`KEEPModel.calibrate()` / `calibrate_bias()` probe seeded N(0,1) tiles by default; every earlier parity figure of this repository was measured on
-N(0,1) tiles too.  This tool evaluates the model -- calibrated exactly as `load_state_dict` leaves it -- on the structured tile families of
-`keep_amd.synth.synth_tile_family` (real-image crops, Beer-Lambert stain fields, glass background, half / half) and on the N(0,1) control:
+Up to round 5 `KEEPModel.calibrate()` / `calibrate_bias()` probed seeded N(0,1) tiles only, and every parity figure of this repository was measured on N(0,1)
+tiles too (`--probe gaussian --bias-probe gaussian` reproduces that build's choices; profiles/r06_offdist_parity_before_repair_gaussian_probe.json).  This tool
+evaluates the model -- calibrated exactly as `load_state_dict` leaves it -- on the structured tile families of `keep_amd.synth.synth_tile_family` (real-image
+crops, Beer-Lambert stain fields, glass background, half / half) and on the N(0,1) control:
 
   oracle leg   `--oracle-tiles` tiles per family in 'comp' and 'strict' against the fp32 CPU oracle (cosines against 64 prompts)
   slide leg    `--tiles` tiles per family in 'comp' against 'strict': every cosine against 64 and 264 prompts, with the bias compensation
-               on and off, plus the all-plain fp16 plan as the yardstick of how hard the family is
+               on and off, plus the all-plain fp16 plan as the yardstick of how hard the family is (`--only-calibrated`: the calibrated plan alone)
 
     python tools/offdist_parity.py [--tiles 12500] [--oracle-tiles 64] [--probe default|mixture] [--out gpurun_out/offdist.json]
 """
