@@ -127,6 +127,16 @@ def test_default_calibration_probes_the_mixture(bench_model):
     for name, v in per.items():                                                        # EVERY group is inside the tolerance, not only the average
         assert v["effective_rms"] * z <= COS_TOL * (1 + 1e-3) and v["exceedance_probability"] <= 1.0 - CONFIDENCE + 1e-9, name
     assert not cal["bias_correction"]                                                  # the mean-input compensation is opt-in since round 6
+    # ... and the plan is the CHEAPEST that verifies, not just one that does: its price in measured knob costs stays a small part of the 33 ms all-plain step
+    # (a search that landed in the expensive end of the walk once kept a plan of 14 ms)
+    from keep_amd import _lib
+    from keep_amd.model import KNOB_COST_MS
+    ca = {_lib.ATTN_PLAIN: 0.0, _lib.ATTN_PROJ_CLS: KNOB_COST_MS["attn_proj_cls"], _lib.ATTN_COMPQKV: KNOB_COST_MS["attn_compqkv"], _lib.ATTN_COMPQKV_PROJ_CLS: KNOB_COST_MS["attn_compqkv_proj_cls"],
+          _lib.ATTN_SPLIT_COMPQKV: KNOB_COST_MS["attn_split_compqkv"], _lib.ATTN_SPLIT: KNOB_COST_MS["attn_split"]}
+    cm = {_lib.MLP_PLAIN: 0.0, _lib.MLP_CLS: KNOB_COST_MS["mlp_cls"], _lib.MLP_COMP_W: KNOB_COST_MS["mlp_comp_w"], _lib.MLP_COMP: KNOB_COST_MS["mlp_comp"], _lib.MLP_SPLIT: 3 * KNOB_COST_MS["mlp_comp"]}
+    price = sum(ca[a] + cm[mm] for a, mm in m.get_plan())
+    print(f"calibrated plan {cal['plan']}: {price:.2f} ms in knob costs; governed by {cal['governing_group']}, predicted {cal['predicted_max_abs_dcos']:.3e}, {len(cal['tried'])} candidates verified")
+    assert price <= 4.5
     sh = cal["variance_shares"]
     assert set(sh["by_group"]) == set(PROBE_FAMILIES) and len(sh["attn"]) == len(sh["mlp"]) == 24
 
