@@ -19,7 +19,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keep_amd import KEEPModel, wsi                                   # noqa: E402
 from keep_amd.config import KEEPShape, small_shape                    # noqa: E402
-from keep_amd.distributed import encode_tiles_sharded                 # noqa: E402
+from keep_amd.distributed import adopt_rank0_plan, encode_tiles_sharded    # noqa: E402
 from keep_amd.synth import synth_prompts, synth_state_dict, synth_tiles_device   # noqa: E402
 
 
@@ -46,6 +46,7 @@ def main():
     model = KEEPModel(shape)
     model.load_state_dict(synth_state_dict(shape, seed=0))
     model.to(dev).eval()
+    adopt_rank0_plan(model, device=dev)       # every rank calibrated on its own at load: the job runs rank 0's plan (a no-op without a process group)
 
     # tiles are generated on the device in units of 256 (a tile's pixels depend only on its global index, so every
     # world size sees the same slide); one or two randn launches per batch, no per-tile Python work
@@ -55,7 +56,7 @@ def main():
     model.reserve(tiles=256)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    feats = encode_tiles_sharded(model.encode_image, args.tiles, load_tiles, batch=256)
+    feats = encode_tiles_sharded(model.encode_image, args.tiles, load_tiles, batch=512)      # 512 tiles per call: two lanes of 256
     torch.cuda.synchronize()
     t_enc = time.perf_counter() - t0
 

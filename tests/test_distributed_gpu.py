@@ -57,6 +57,22 @@ def test_sharded_encode_through_rccl_matches_direct_call(nccl_world1):
     assert torch.equal(load(10, 100), torch.cat([load(10, 64), load(64, 100)]))
 
 
+def test_rank0_plan_adoption_through_rccl(nccl_world1):
+    """`adopt_rank0_plan` with the real engine on the `nccl` group (world size 1: the broadcast runs, the plan it hands back is the engine's own)."""
+    from keep_amd import KEEPModel
+    from keep_amd.config import small_shape
+    from keep_amd.distributed import adopt_rank0_plan, assert_same_setting
+    from keep_amd.synth import synth_state_dict
+    dev = torch.device("cuda", 0)
+    shape = small_shape(2, 2)
+    m = KEEPModel(shape, towers=("image",))
+    m.load_state_dict(synth_state_dict(shape, seed=3, text=False), strict=True)
+    m.to(dev).eval()
+    own, margin = m.get_plan(), m.get_option("label_margin")
+    assert adopt_rank0_plan(m, device=dev) == [tuple(x) for x in own] and m.get_plan() == own and m.get_option("label_margin") == margin
+    assert len(assert_same_setting([m.get_option("precision")] + [float(v) for am in m.get_plan() for v in am], "plan", device=dev)) == 1
+
+
 def test_bench_distributed_leg_runs_on_nccl():
     env = dict(os.environ, KEEP_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))      # bench.py sets the RCCL environment itself (keep_amd.distributed.rccl_env)
