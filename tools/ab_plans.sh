@@ -1,3 +1,5 @@
+#!/bin/bash
+# Run ON THE GPU BOX: two-lane 256-tile step time of explicit per-block plans, interleaved, three rounds (KEEP_CALIBRATE=0: no calibration kernels in between).
 export KEEP_CALIBRATE=0
 for rep in 1 2 3; do
 for plan in "attn:224444444444444444444440 mlp:444444444444444444444444" "attn:255444444444444444444440 mlp:444444444444444444444444" "attn:254444444444444444444440 mlp:444444444444444444444444"; do

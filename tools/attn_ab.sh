@@ -1,3 +1,5 @@
+#!/bin/bash
+# Run ON THE GPU BOX: rocprofv3 kernel stats of tools/attn_time.py for the experiment builds keep_amd/libkeep_hip_trim{0,1,2}.so (-DKEEP_ATTN_TRIM=v, tools/experiments/attention_softmax_trim.patch applied).
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for rep in 1 2; do for v in 0 1 2; do

@@ -1,3 +1,5 @@
+#!/bin/bash
+# Run ON THE GPU BOX: rocprofv3 kernel stats of the small-M kernels (CLS-row chain) with the 128x128 kernel on (skinny_wide=1) and off, one internal stream, explicit plan.
 set -u
 REPO=$(pwd); mkdir -p gpurun_out/skinny
 export KEEP_CALIBRATE=0
