@@ -58,13 +58,15 @@ def main():
     ap.add_argument("--seed", type=int, default=7000)
     ap.add_argument("--probe", default="mixture", choices=["mixture", "gaussian"], help="what the load-time calibration probes (KEEPModel.calibration_probe)")
     ap.add_argument("--bias-probe", default=None, choices=["mixture", "gaussian", "off"], help="what calibrate_bias probes (default: the same as --probe)")
+    ap.add_argument("--weight-family", default="default", help="weight family of keep_amd.synth (default | heavy_tail | small_ls)")
+    ap.add_argument("--weight-seed", type=int, default=0)
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--only-calibrated", action="store_true", help="skip the no-compensation / all-plain yardsticks (full-size runs)")
     ap.add_argument("--out", default="gpurun_out/offdist_parity.json")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     shape = KEEPShape()
-    sd = synth_state_dict(shape, seed=0)
+    sd = synth_state_dict(shape, seed=args.weight_seed, family=args.weight_family)
     model = KEEPModel(shape)
     model.calibration_probe = args.probe
     if args.bias_probe is not None and args.bias_probe != args.probe:
@@ -81,7 +83,7 @@ def main():
     own = model.get_plan()
     depth = len(own)
     bias_was = int(model.get_option("bias_correction"))
-    res = {"calibration": model.calibration, "families": {}}
+    res = {"calibration": model.calibration, "families": {}, "weight_family": args.weight_family, "weight_seed": args.weight_seed}
     xb = synth_tiles_device(0, 256, dev, torch.bfloat16, seed=1234)
     for _ in range(5):
         model.encode_image(xb)
