@@ -721,6 +721,22 @@ def test_similarity_9_to_64_prompts_fused_kernel(N, P):
 
 
 
+def test_config5_probability_map_at_full_size_against_the_oracle():
+    """BASELINE config 5 at its stated size: the fp16 probability map softmax(10 cos) of 100 000 tiles x 2 classes, EVERY entry against the fp32 CPU oracle
+    (`O.sim_softmax(O.similarity(...))`: a 0.3 GFLOP matmul on the host).  Tolerance: half an fp16 ulp at 0.5 (probabilities in [0.5, 1) are stored to 2^-11) + the
+    fp32 path's 1e-6; rows sum to 1 within one ulp."""
+    import bench
+    m = KEEPModel()
+    r = bench.config5(m, torch.device("cuda", 0), n=100_000)
+    print(f"[config 5, 100 000 x 2] {r['us']} us, {r['GBps']} GB/s ({r['frac_of_hbm_peak']} of the HBM peak); max |err| vs the oracle {r['max_abs_err_vs_oracle']:.3e}")
+    assert r["tiles_checked_against_oracle"] == 100_000 and r["within_fp16_rounding_of_oracle"] and r["max_abs_err_vs_oracle"] <= 2.0 ** -12 + 1e-6
+    g = torch.Generator().manual_seed(56)
+    feats = torch.nn.functional.normalize(torch.randn(4096, 768, generator=g), dim=-1).cuda()
+    cls = torch.nn.functional.normalize(torch.randn(2, 768, generator=g), dim=-1).cuda()
+    p = m.similarity(feats, cls, scale=10.0, mode="softmax_f16").float()
+    assert (p.sum(1) - 1.0).abs().max() <= 2.0 ** -11 + 1e-6
+
+
 def test_similarity_modes():
     m = KEEPModel()
     g = torch.Generator().manual_seed(5)
